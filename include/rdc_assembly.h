@@ -1,0 +1,207 @@
+/*
+ * rdc_assembly.h — C-ABI of the MI355X-native element-assembly path of rdcFEs.
+ *
+ * This is the drop-in boundary.  Every entry point replaces a piece of
+ * what the reference does inside its libMesh assemble callbacks:
+ *
+ *   reference (file:line, under the upstream tree)             this header
+ *   ---------------------------------------------------------  ---------------------------
+ *   mesh.active_local_element_ptr_range()   src/pihna.C:383     rdc_mesh_upload
+ *   DofMap::dof_indices                     src/pihna.C:385-394 rdc_mesh_upload (dof = node*nvar+var)
+ *   es.init() sparsity pattern              src/pihna.C:48      rdc_csr_dims / rdc_csr_pattern_download
+ *   system.old_solution(dof)                src/pihna.C:433     rdc_field_upload(RDC_FIELD_OLD_SOLUTION)
+ *   TD_system / RT_system.current_solution  src/ripf.C:470,477  rdc_field_upload(RDC_FIELD_AUX_NODAL)
+ *   aux_system undeformed coordinates       src/solid_system.C:221-229  rdc_field_upload(RDC_FIELD_UNDEFORMED_XYZ)
+ *   fibre_sys / subdomain_id                src/solid_system.C:183-216  rdc_field_upload(RDC_FIELD_ELEM_FIBRE), rdc_solid_set_materials
+ *   mesh node positions (moving mesh)       src/solid_system.C:103-123  rdc_mesh_update_coords
+ *   assemble_pihna                          src/pihna.C:318-758 rdc_assemble_pihna
+ *   assemble_ripf                           src/ripf.C:337-673  rdc_assemble_ripf
+ *   assemble_hcc                            src/coupled_hcc.C:414-649   rdc_assemble_hcc
+ *   SolidSystem::element_time_derivative    src/solid_system.C:146-271  rdc_solid_assemble
+ *   SolidSystem::side_time_derivative       src/solid_system.C:273-371  rdc_solid_assemble (sides set by rdc_solid_set_sides)
+ *   matrix.add_matrix / rhs->add_vector     src/pihna.C:754-755 results: rdc_csr_values_device_ptr / rdc_csr_download
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns an int status (RDC_OK == 0);
+ *     rdc_last_error() gives a human-readable message for the last failure on a context.
+ *   - all caller buffers are caller-owned; the library copies what it needs.
+ *   - one context == one GPU == one mesh partition == one system of `nvar` FIRST-LAGRANGE variables.
+ *     Calls on one context are not thread-safe (the reference callback is single-threaded per rank).
+ *   - DoF numbering: dof = local_node * nvar + var  (libMesh variable-group numbering).
+ *   - nodes [0, n_owned_nodes) are owned: their matrix rows / rhs entries are assembled completely
+ *     on this context.  Nodes [n_owned_nodes, n_nodes) are ghosts (values supplied by halo exchange).
+ *     The element list must contain every element touching an owned node (owned + one ghost layer).
+ *   - matrix = scalar CSR (PETSc AIJ layout) over the owned rows, column indices are LOCAL dof ids
+ *     (owned and ghost), sorted ascending within a row.  Row r = node*nvar + var.
+ *   - there is NO CPU fallback: without a usable HIP device rdc_ctx_create fails with RDC_ERR_HIP.
+ */
+#ifndef RDC_ASSEMBLY_H
+#define RDC_ASSEMBLY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDC_ABI_VERSION 1
+
+/* status codes */
+#define RDC_OK               0
+#define RDC_ERR_INVALID      1   /* bad argument (null pointer, bad size, out-of-range index) */
+#define RDC_ERR_HIP          2   /* HIP runtime failure / no device */
+#define RDC_ERR_STATE        3   /* call order violated (e.g. assemble before mesh upload) */
+#define RDC_ERR_UNSUPPORTED  4   /* element type / model combination not implemented */
+#define RDC_ERR_ALLOC        5   /* host or device allocation failed */
+
+/* element types (value == nodes per element) */
+#define RDC_TET4 4
+#define RDC_HEX8 8
+
+/* scatter strategies */
+#define RDC_SCATTER_AUTO       0  /* pick the fastest implemented for (model, element type) */
+#define RDC_SCATTER_COLOURED   1  /* element-parallel, colour batches, plain read-modify-write, no atomics */
+#define RDC_SCATTER_ROWGATHER  2  /* row-owner gather: every CSR value written exactly once, streaming stores */
+
+/* kernel variants (test / benchmarking hook) */
+#define RDC_VARIANT_AUTO     0  /* factored TET4 kernels where available, generic otherwise */
+#define RDC_VARIANT_GENERIC  1  /* always the generic quadrature-loop kernels */
+
+/* fields */
+#define RDC_FIELD_OLD_SOLUTION   0  /* [n_nodes][nvar]   system.old_local_solution                     */
+#define RDC_FIELD_AUX_NODAL      1  /* [n_nodes][naux]   RIPF: {cc_dtime, fb_dtime, RT_total}          */
+#define RDC_FIELD_UNDEFORMED_XYZ 2  /* [n_nodes][3]      solid: "SolidSystem::auxiliary"               */
+#define RDC_FIELD_ELEM_FIBRE     3  /* [n_elem][3]       solid: fibre direction, vars 0..2 of "::fibre" */
+#define RDC_FIELD_COUNT          4
+
+typedef struct rdc_ctx rdc_ctx;
+
+/* ---- parameters: POD mirrors of the string-keyed es.parameters the callbacks read ---- */
+
+/* src/pihna.C:358-381.  necrosis_* are the RAW input values; the division by
+ * cells_max_capacity (src/pihna.C:364-366) happens inside the library, as in the reference. */
+typedef struct rdc_pihna_params {
+  double time_step;                    /* "time_step"                   */
+  double cells_min_capacity;           /* "cells_min_capacity"  Lambda_k */
+  double cells_max_capacity;           /* "cells_max_capacity"  Kappa_k  */
+  double cytokines_max_capacity;       /* "cytokines_max_capacity" Kappa_a */
+  double cells_max_capacity_exponent;  /* "cells_max_capacity/exponent" ek */
+  double necrosis_c, necrosis_h, necrosis_v;   /* "necrosis/c|h|v" */
+  double diffuse_c, taxis_c;           /* "diffuse/c", "taxis/c" */
+  double diffuse_h, taxis_h;           /* "diffuse/h", "taxis/h" */
+  double produce_c;                    /* "produce/c" */
+  double switch_c2h, switch_h2c, switch_h2n;   /* "switch/c/to/h" ... */
+  double diffuse_v, taxis_v, produce_v;        /* "diffuse/v", "taxis/v", "produce/v" */
+  double secrete_a_c, secrete_a_h;     /* "secrete/a/from/c|h" */
+  double uptake_a_v, decay_a;          /* "uptake/a/from/v", "decay/a" */
+} rdc_pihna_params;
+
+/* src/ripf.C:377-408.  lambda_RT_r / omicro_RT_r: if 0 the reference substitutes the runtime
+ * value "RT_dose/total/max" (src/ripf.C:398-403); pass that in RT_dose_total_max. */
+typedef struct rdc_ripf_params {
+  double time_step;
+  double VolFr_stroma, VolFr_parenchyma, VolFr_exponent, VolFr_min_vacant, VolFr_max_vacant;
+  double phi_cc_B, phi_cc_D, phi_cc, phi_fb_B, phi_fb_D, phi_fb, phi_tol;
+  double kappa, kappa_RT_c, delta, delta_RT_a, delta_RT_b;
+  double lambda, lambda_RT_r, lambda_HU_r;
+  double omicro, omicro_RT_r, omicro_fb_b;
+  double omega, diffusion, haptotaxis, radiotaxis;
+  int32_t RT_dose_total_max;           /* es.parameters.get<int>("RT_dose/total/max") */
+  int32_t _pad;
+} rdc_ripf_params;
+
+/* src/coupled_hcc.C:450-461 (necrosis_* raw; divided by cells/max_capacity inside). */
+typedef struct rdc_hcc_params {
+  double time_step;
+  double cells_min_capacity, cells_max_capacity, cells_max_capacity_exponent;
+  double produce_l;
+  double diffuse_c, mechano_c, produce_c;
+  double necrosis_l, necrosis_c, necrosis_pressure;
+} rdc_hcc_params;
+
+/* per-subdomain material, src/solid_system.C:183-190 */
+typedef struct rdc_solid_material {
+  double Young, Poisson, FibreStiffness;
+  double rate[3];                      /* VolumetricStretchRatio/rate_0..2 */
+} rdc_solid_material;
+
+/* src/solid_system.C:181,234,291,306 */
+typedef struct rdc_solid_params {
+  double pseudo_time;                  /* "pseudo_time" */
+  double displacement_penalty;         /* "BCs/displacement_penalty" */
+  int32_t use_symmetry;                /* "solver/assembly_use_symmetry" */
+  int32_t _pad;
+} rdc_solid_params;
+
+/* ---- context ---- */
+int rdc_abi_version(void);
+int rdc_ctx_create(int device_ordinal, rdc_ctx** out);
+int rdc_ctx_destroy(rdc_ctx* ctx);
+/* message for the last failing call on ctx (ctx may be NULL: last rdc_ctx_create failure) */
+const char* rdc_last_error(const rdc_ctx* ctx);
+/* run all work of this context on an externally created hipStream_t (NULL = default stream) */
+int rdc_set_stream(rdc_ctx* ctx, void* hip_stream);
+int rdc_synchronize(rdc_ctx* ctx);
+int rdc_set_scatter(rdc_ctx* ctx, int strategy);
+int rdc_get_scatter(const rdc_ctx* ctx, int* strategy);
+int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
+
+/* ---- mesh / pattern (one-time set-up; replaces es.init()) ---- */
+/* conn: [n_elem][elem_type] local node ids, libMesh/Gmsh node order; xyz: [n_node][3]. */
+int rdc_mesh_upload(rdc_ctx* ctx, int elem_type, int64_t n_elem, int64_t n_node,
+                    int64_t n_owned_nodes, const uint32_t* conn, const double* xyz, int nvar);
+/* moving mesh: new CURRENT node positions (host pointer), same numbering */
+int rdc_mesh_update_coords(rdc_ctx* ctx, const double* xyz);
+/* device pointer of the current coordinates [n_node][3] (e.g. to update them in place on the GPU) */
+int rdc_mesh_coords_device_ptr(rdc_ctx* ctx, double** d_xyz);
+int rdc_mesh_dims(const rdc_ctx* ctx, int64_t* n_elem, int64_t* n_node, int64_t* n_owned_nodes,
+                  int* elem_type, int* nvar, int* n_colours);
+int rdc_csr_dims(const rdc_ctx* ctx, int64_t* n_rows, int64_t* nnz);
+int rdc_csr_pattern_download(const rdc_ctx* ctx, int64_t* row_ptr, int32_t* col_idx);
+/* element colouring used by the coloured scatter (test hook): colour id per element */
+int rdc_mesh_colours_download(const rdc_ctx* ctx, int32_t* colour_of_elem);
+
+/* ---- fields ---- */
+int rdc_field_upload(rdc_ctx* ctx, int field, const double* host, int64_t count);
+int rdc_field_download(rdc_ctx* ctx, int field, double* host, int64_t count);
+/* library-owned device storage of a field (allocated on first use) */
+int rdc_field_device_ptr(rdc_ctx* ctx, int field, int64_t count, double** d_ptr);
+/* use caller-owned device memory for a field (must stay valid until rebound / ctx destroyed) */
+int rdc_field_bind_device(rdc_ctx* ctx, int field, double* d_ptr, int64_t count);
+
+/* ---- solid-only set-up ---- */
+/* subdomain index per element (index into materials[]), materials table */
+int rdc_solid_set_materials(rdc_ctx* ctx, const int32_t* elem_material, int32_t n_materials,
+                            const rdc_solid_material* materials);
+/* boundary sides with a displacement BC: element id, libMesh side number, prescribed displacement
+ * (NaN component = unconstrained, src/solid_system.C:346,358) */
+int rdc_solid_set_sides(rdc_ctx* ctx, int64_t n_sides, const int64_t* side_elem,
+                        const int32_t* side_id, const double* side_displacement /* [n_sides][3] */);
+
+/* ---- the hot path: one call == one invocation of the reference's assemble callback ----
+ * Pre: mesh + fields uploaded.  Post: CSR values and rhs hold the assembled sums for the owned rows
+ * (the library zeroes/overwrites them itself: libMesh zeroes matrix & rhs before the callback). */
+int rdc_assemble_pihna(rdc_ctx* ctx, const rdc_pihna_params* p);
+int rdc_assemble_ripf(rdc_ctx* ctx, const rdc_ripf_params* p);
+int rdc_assemble_hcc(rdc_ctx* ctx, const rdc_hcc_params* p);
+/* residual (+ Jacobian if request_jacobian) of the SolidSystem; nvar must be 3 */
+int rdc_solid_assemble(rdc_ctx* ctx, const rdc_solid_params* p, int request_jacobian);
+
+/* ---- results ---- */
+int rdc_csr_values_device_ptr(rdc_ctx* ctx, double** d_val, double** d_rhs);
+int rdc_csr_download(rdc_ctx* ctx, double* val, double* rhs);
+
+/* ---- post-solve nodal kernel: negativity clamp of check_solution,
+ * src/pihna.C:785-790, applied in place to a device-resident field ---- */
+int rdc_clamp_nonnegative(rdc_ctx* ctx, int field);
+
+/* ---- instrumentation ---- */
+/* when enabled every rdc_assemble_* brackets its kernels with HIP events on the context stream */
+int rdc_timing_enable(rdc_ctx* ctx, int on);
+/* device time of the last assemble call in ms (valid after the stream has been synchronised) */
+int rdc_timing_last_ms(rdc_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDC_ASSEMBLY_H */

@@ -1,0 +1,881 @@
+/*
+ * rdc_oracle.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU (FP64, scalar) restatement of the element-assembly hot path of rdcFEs, used as the
+ * checker for the HIP path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this; the product (rdcfes_amd/, include/) never does.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or expected outputs
+ * (SURVEY.md §4), and it cannot be built here (needs libMesh d3bda6c + PETSc 746207a, neither
+ * present; no stand-in headers are written for them).  This restatement is pinned only by the
+ * known-answer tests we author in tests/test_oracle_*.py (partition of unity, quadrature
+ * exactness, uniform-state closed forms, finite-difference Jacobian checks, F=I limits).
+ *
+ * Each function cites the reference lines it follows (paths relative to the upstream tree).
+ * Third-party arithmetic that is NOT in the upstream tree (libMesh d3bda6c): FIRST LAGRANGE
+ * shape functions on TET4/HEX8, QGauss(THIRD) rules, FEMap (J, JxW) — restated from the
+ * published definitions, SURVEY.md App. B.
+ *
+ * Loop order is kept reference-faithful on purpose (elem -> qp -> i -> j, dense Ke/Fe, then a
+ * per-entry sorted-row insertion like MatSetValues) so that the same code doubles as the
+ * "port" CPU baseline.
+ */
+#include "rdc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * FE tables: libMesh FIRST LAGRANGE on TET4 / HEX8, QGauss(3, THIRD)   [SURVEY App. B.2-B.4]
+ * ------------------------------------------------------------------------------------------ */
+
+/* TET4 5-point rule with one negative weight (exact for cubics). */
+static const double TET_QP[5][3] = {
+  {0.25, 0.25, 0.25},
+  {0.5, 1.0 / 6.0, 1.0 / 6.0},
+  {1.0 / 6.0, 0.5, 1.0 / 6.0},
+  {1.0 / 6.0, 1.0 / 6.0, 0.5},
+  {1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0}};
+static const double TET_QW[5] = {-2.0 / 15.0, 0.075, 0.075, 0.075, 0.075};
+
+/* HEX8 reference corners (libMesh / Gmsh order). */
+static const double HEX_C[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1},
+                                   {-1, -1, 1},  {1, -1, 1},  {1, 1, 1},  {-1, 1, 1}};
+
+int oracle_nqp(int elem_type) { return elem_type == 4 ? 5 : (elem_type == 8 ? 8 : -1); }
+
+static void ref_shape(int elem_type, const double xi[3], double* N, double (*dN)[3]) {
+  if (elem_type == 4) {
+    N[0] = 1.0 - xi[0] - xi[1] - xi[2];
+    N[1] = xi[0];
+    N[2] = xi[1];
+    N[3] = xi[2];
+    dN[0][0] = dN[0][1] = dN[0][2] = -1.0;
+    dN[1][0] = 1; dN[1][1] = 0; dN[1][2] = 0;
+    dN[2][0] = 0; dN[2][1] = 1; dN[2][2] = 0;
+    dN[3][0] = 0; dN[3][1] = 0; dN[3][2] = 1;
+  } else {
+    for (int n = 0; n < 8; n++) {
+      const double a = 1.0 + HEX_C[n][0] * xi[0], b = 1.0 + HEX_C[n][1] * xi[1],
+                   c = 1.0 + HEX_C[n][2] * xi[2];
+      N[n] = 0.125 * a * b * c;
+      dN[n][0] = 0.125 * HEX_C[n][0] * b * c;
+      dN[n][1] = 0.125 * a * HEX_C[n][1] * c;
+      dN[n][2] = 0.125 * a * b * HEX_C[n][2];
+    }
+  }
+}
+
+static void ref_qpoint(int elem_type, int q, double xi[3], double* w) {
+  if (elem_type == 4) {
+    xi[0] = TET_QP[q][0]; xi[1] = TET_QP[q][1]; xi[2] = TET_QP[q][2];
+    *w = TET_QW[q];
+  } else {
+    /* tensor 2-point Gauss, x fastest */
+    const double g = 0.57735026918962576451; /* 1/sqrt(3) */
+    xi[0] = (q & 1) ? g : -g;
+    xi[1] = (q & 2) ? g : -g;
+    xi[2] = (q & 4) ? g : -g;
+    *w = 1.0;
+  }
+}
+
+static double det3(const double m[3][3]) {
+  return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) -
+         m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+         m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+static void inv3(const double m[3][3], double r[3][3]) {
+  const double d = det3(m), s = 1.0 / d;
+  r[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * s;
+  r[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * s;
+  r[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * s;
+  r[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * s;
+  r[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * s;
+  r[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * s;
+  r[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * s;
+  r[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * s;
+  r[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * s;
+}
+
+/* fe->reinit(elem): phi[q][n], dphi[q][n][3] (physical gradients), JxW[q].
+ * (libMesh FEMap: J = dx/dxi, dphi = dN/dxi . J^-1, JxW = det(J) * w.)   src/pihna.C:420 */
+int oracle_fe_reinit(int elem_type, const double* X /*[nen][3]*/, double* phi, double* dphi,
+                     double* JxW) {
+  const int nen = elem_type, nqp = oracle_nqp(elem_type);
+  if (nqp < 0) return 1;
+  for (int q = 0; q < nqp; q++) {
+    double xi[3], w, N[8], dN[8][3], J[3][3] = {{0}}, Ji[3][3];
+    ref_qpoint(elem_type, q, xi, &w);
+    ref_shape(elem_type, xi, N, dN);
+    for (int n = 0; n < nen; n++)
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) J[r][c] += X[3 * n + r] * dN[n][c]; /* dx_r / dxi_c */
+    inv3(J, Ji);                                                         /* dxi_c / dx_r = Ji[c][r] */
+    for (int n = 0; n < nen; n++) {
+      phi[q * nen + n] = N[n];
+      for (int r = 0; r < 3; r++)
+        dphi[(q * nen + n) * 3 + r] = dN[n][0] * Ji[0][r] + dN[n][1] * Ji[1][r] + dN[n][2] * Ji[2][r];
+    }
+    JxW[q] = det3(J) * w;
+  }
+  return 0;
+}
+
+#define PHI(n) phi[q * nen + (n)]
+#define DPHI(n, d) dphi[(q * nen + (n)) * 3 + (d)]
+static inline double dot_dphi(const double g[3], const double* dphi, int q, int nen, int n) {
+  return g[0] * DPHI(n, 0) + g[1] * DPHI(n, 1) + g[2] * DPHI(n, 2);
+}
+static inline double dphi_dphi(const double* dphi, int q, int nen, int a, int b) {
+  return DPHI(a, 0) * DPHI(b, 0) + DPHI(a, 1) * DPHI(b, 1) + DPHI(a, 2) * DPHI(b, 2);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PIHNA integrand                                                    src/pihna.C:427-750
+ * u: [nen][5] old solution (n,c,h,v,a);  Ke: [5nen][5nen] var-major (src/pihna.C:408-410)
+ * ------------------------------------------------------------------------------------------ */
+void oracle_pihna_element(int nen, int nqp, const double* phi, const double* dphi,
+                          const double* JxW, const double* u, const rdc_pihna_params* P,
+                          double* Ke, double* Fe) {
+  const int nd = 5 * nen;
+  memset(Ke, 0, sizeof(double) * nd * nd);
+  memset(Fe, 0, sizeof(double) * nd);
+  /* src/pihna.C:358-381 */
+  const double DT_2 = P->time_step / 2.0;
+  const double Lambda_k = P->cells_min_capacity, Kappa_k = P->cells_max_capacity,
+               Kappa_a = P->cytokines_max_capacity, ek = P->cells_max_capacity_exponent;
+  const double nec_c = P->necrosis_c / Kappa_k, nec_h = P->necrosis_h / Kappa_k,
+               nec_v = P->necrosis_v / Kappa_k;
+  const double prod_c = P->produce_c, c2h = P->switch_c2h, h2c = P->switch_h2c,
+               h2n = P->switch_h2n, prod_v = P->produce_v;
+  const double sec_c = P->secrete_a_c, sec_h = P->secrete_a_h, upt = P->uptake_a_v,
+               dec = P->decay_a;
+#define KE(a, b) Ke[((a) * nen + i) * nd + (b) * nen + j]
+#define FE(a) Fe[(a) * nen + i]
+  for (int q = 0; q < nqp; q++) {
+    /* src/pihna.C:429-442 */
+    double n_ = 0, c_ = 0, h_ = 0, v_ = 0, a_ = 0;
+    double Gc[3] = {0, 0, 0}, Gh[3] = {0, 0, 0}, Gv[3] = {0, 0, 0}, Ga[3] = {0, 0, 0};
+    for (int l = 0; l < nen; l++) {
+      n_ += PHI(l) * u[5 * l + 0];
+      c_ += PHI(l) * u[5 * l + 1];
+      h_ += PHI(l) * u[5 * l + 2];
+      v_ += PHI(l) * u[5 * l + 3];
+      a_ += PHI(l) * u[5 * l + 4];
+      for (int d = 0; d < 3; d++) {
+        Gc[d] += DPHI(l, d) * u[5 * l + 1];
+        Gh[d] += DPHI(l, d) * u[5 * l + 2];
+        Gv[d] += DPHI(l, d) * u[5 * l + 3];
+        Ga[d] += DPHI(l, d) * u[5 * l + 4];
+      }
+    }
+    /* crowding function, src/pihna.C:444-472; the four derivatives are identical */
+    double Tau, dT;
+    {
+      const double Te = (n_ + c_ + h_ + v_) / Kappa_k;
+      if (Te <= 0.0) { Tau = 1.0; dT = 0.0; }
+      else if (Te >= 1.0) { Tau = 0.0; dT = 0.0; }
+      else { Tau = pow(1.0 - Te, ek); dT = (-ek / Kappa_k) * pow(1.0 - Te, ek - 1.0); }
+    }
+    /* vascular fraction, src/pihna.C:474-499 (NaN when c+h+v == 0 falls into the else branch) */
+    double Ve, Ve_dc, Ve_dh, Ve_dv;
+    {
+      const double Ve_ = v_ / (c_ + h_ + v_);
+      if (Ve_ <= 0.0) { Ve = 0.0; Ve_dc = Ve_dh = Ve_dv = 0.0; }
+      else if (Ve_ >= 1.0) { Ve = 1.0; Ve_dc = Ve_dh = Ve_dv = 0.0; }
+      else {
+        Ve = Ve_;
+        Ve_dc = Ve_dh = -Ve_ / (c_ + h_ + v_);
+        Ve_dv = (1.0 - Ve_) / (c_ + h_ + v_);
+      }
+    }
+    /* src/pihna.C:501-509 */
+    const double Ua = a_ / (a_ + Kappa_a), Ua_da = 1.0 / (a_ + Kappa_a) - Ua / (a_ + Kappa_a);
+    const double dif_c = (c_ > Lambda_k ? P->diffuse_c : 0.0), tax_c = (c_ > Lambda_k ? P->taxis_c : 0.0),
+                 dif_h = (h_ > Lambda_k ? P->diffuse_h : 0.0), tax_h = (h_ > Lambda_k ? P->taxis_h : 0.0),
+                 dif_v = (v_ > Lambda_k ? P->diffuse_v : 0.0), tax_v = (v_ > Lambda_k ? P->taxis_v : 0.0);
+    const double W = JxW[q];
+    for (int i = 0; i < nen; i++) {
+      const double pi = PHI(i);
+      const double gc = dot_dphi(Gc, dphi, q, nen, i), gh = dot_dphi(Gh, dphi, q, nen, i),
+                   gv = dot_dphi(Gv, dphi, q, nen, i), ga = dot_dphi(Ga, dphi, q, nen, i);
+      /* right-hand side, src/pihna.C:514-566 */
+      FE(0) += W * (n_ * pi + DT_2 * (nec_c * c_ * n_ * pi + nec_h * h_ * n_ * pi + nec_v * v_ * n_ * pi +
+                                      h2n * (1.0 - Ve) * h_ * pi));
+      FE(1) += W * (c_ * pi + DT_2 * (prod_c * Tau * c_ * pi - c2h * (1.0 - Ve) * c_ * pi + h2c * Ve * h_ * pi -
+                                      nec_c * c_ * n_ * pi - dif_c * Tau * gc - tax_c * Tau * c_ * gv));
+      FE(2) += W * (h_ * pi + DT_2 * (c2h * (1.0 - Ve) * c_ * pi - h2c * Ve * h_ * pi - nec_h * h_ * n_ * pi -
+                                      dif_h * Tau * gh - tax_h * Tau * h_ * gv - h2n * (1.0 - Ve) * h_ * pi));
+      FE(3) += W * (v_ * pi + DT_2 * (prod_v * Tau * Ua * v_ * pi - nec_v * v_ * n_ * pi - dif_v * Tau * gv -
+                                      tax_v * Tau * v_ * ga));
+      FE(4) += W * (a_ * pi + DT_2 * (sec_c * c_ * pi + sec_h * h_ * pi - upt * v_ * a_ * pi - dec * a_ * pi));
+      for (int j = 0; j < nen; j++) {
+        const double pj = PHI(j), pp = pj * pi, dd = dphi_dphi(dphi, q, nen, j, i);
+        /* n-row, src/pihna.C:571-597 */
+        KE(0, 0) += W * (pp - DT_2 * (nec_c * c_ * pp + nec_h * h_ * pp + nec_v * v_ * pp));
+        KE(0, 1) += W * (-DT_2 * (nec_c * pj * n_ * pi + h2n * (-Ve_dc) * pj * h_ * pi));
+        KE(0, 2) += W * (-DT_2 * (nec_h * pj * n_ * pi + h2n * (-Ve_dh) * pj * h_ * pi + h2n * (1.0 - Ve) * pp));
+        KE(0, 3) += W * (-DT_2 * (nec_v * pj * n_ * pi + h2n * (-Ve_dv) * pj * h_ * pi));
+        /* c-row, src/pihna.C:599-641 */
+        KE(1, 0) += W * (-DT_2 * (prod_c * dT * pj * c_ * pi - nec_c * c_ * pp - dif_c * dT * pj * gc -
+                                  tax_c * dT * pj * c_ * gv));
+        KE(1, 1) += W * (pp - DT_2 * (prod_c * Tau * pp + prod_c * dT * pj * c_ * pi - c2h * (1.0 - Ve) * pp -
+                                      c2h * (-Ve_dc) * pj * c_ * pi + h2c * Ve_dc * pj * h_ * pi -
+                                      nec_c * pj * n_ * pi - dif_c * dT * pj * gc - dif_c * Tau * dd -
+                                      tax_c * dT * pj * c_ * gv - tax_c * Tau * pj * gv));
+        KE(1, 2) += W * (-DT_2 * (prod_c * dT * pj * c_ * pi - c2h * (-Ve_dh) * pj * c_ * pi +
+                                  h2c * Ve_dh * pj * h_ * pi + h2c * Ve * pp - dif_c * dT * pj * gc -
+                                  tax_c * dT * pj * c_ * gv));
+        KE(1, 3) += W * (-DT_2 * (prod_c * dT * pj * c_ * pi - c2h * (-Ve_dv) * pj * c_ * pi +
+                                  h2c * Ve_dv * pj * h_ * pi - dif_c * dT * pj * gc -
+                                  tax_c * dT * pj * c_ * gv - tax_c * Tau * c_ * dd));
+        /* h-row, src/pihna.C:643-684 */
+        KE(2, 0) += W * (-DT_2 * (-nec_h * h_ * pp - dif_h * dT * pj * gh - tax_h * dT * pj * h_ * gv));
+        KE(2, 1) += W * (-DT_2 * (c2h * (1.0 - Ve) * pp + c2h * (-Ve_dc) * pj * c_ * pi - h2c * Ve_dc * pj * h_ * pi -
+                                  dif_h * dT * pj * gh - tax_h * dT * pj * h_ * gv -
+                                  h2n * (-Ve_dc) * pj * h_ * pi));
+        KE(2, 2) += W * (pp - DT_2 * (c2h * (-Ve_dh) * pj * c_ * pi - h2c * Ve_dh * pj * h_ * pi - h2c * Ve * pp -
+                                      nec_h * pj * n_ * pi - dif_h * dT * pj * gh - dif_h * Tau * dd -
+                                      tax_h * dT * pj * h_ * gv - tax_h * Tau * pj * gv -
+                                      h2n * (-Ve_dh) * pj * h_ * pi - h2n * (1.0 - Ve) * pp));
+        KE(2, 3) += W * (-DT_2 * (c2h * (-Ve_dv) * pj * c_ * pi - h2c * Ve_dv * pj * h_ * pi - dif_h * dT * pj * gh -
+                                  tax_h * dT * pj * h_ * gv - tax_h * Tau * h_ * dd -
+                                  h2n * (-Ve_dv) * pj * h_ * pi));
+        /* v-row, src/pihna.C:686-724 */
+        KE(3, 0) += W * (-DT_2 * (prod_v * dT * pj * Ua * v_ * pi - nec_v * v_ * pp - dif_v * dT * pj * gv -
+                                  tax_v * dT * pj * v_ * ga));
+        KE(3, 1) += W * (-DT_2 * (prod_v * dT * pj * Ua * v_ * pi - dif_v * dT * pj * gv - tax_v * dT * pj * v_ * ga));
+        KE(3, 2) += W * (-DT_2 * (prod_v * dT * pj * Ua * v_ * pi - dif_v * dT * pj * gv - tax_v * dT * pj * v_ * ga));
+        KE(3, 3) += W * (pp - DT_2 * (prod_v * dT * pj * Ua * v_ * pi - nec_v * pj * n_ * pi - dif_v * dT * pj * gv -
+                                      dif_v * Tau * dd - tax_v * dT * pj * v_ * ga - tax_v * Tau * pj * ga));
+        KE(3, 4) += W * (-DT_2 * (prod_v * Tau * Ua_da * pj * v_ * pi - tax_v * Tau * v_ * dd));
+        /* a-row, src/pihna.C:726-747 */
+        KE(4, 1) += W * (-DT_2 * (sec_c * pp));
+        KE(4, 2) += W * (-DT_2 * (sec_h * pp));
+        KE(4, 3) += W * (-DT_2 * (-upt * pj * a_ * pi));
+        KE(4, 4) += W * (pp - DT_2 * (-upt * v_ * pp - dec * pp));
+      }
+    }
+  }
+#undef KE
+#undef FE
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RIPF integrand                                                      src/ripf.C:449-665
+ * u: [nen][3] (HU,cc,fb); aux: [nen][3] = {cc_dtime, fb_dtime, RT_total}
+ * (TD vars 1,2 src/ripf.C:470-471; RT var 2 src/ripf.C:477-478).
+ * ------------------------------------------------------------------------------------------ */
+static inline double pow2(double v) { return v * v; }                          /* src/utils.h:69 */
+static inline double apply_lbound(double L, double X) { return X < L ? L : X; } /* src/utils.h:86 */
+
+void oracle_ripf_element(int nen, int nqp, const double* phi, const double* dphi,
+                         const double* JxW, const double* u, const double* aux,
+                         const rdc_ripf_params* P, double* Ke, double* Fe) {
+  const int nd = 3 * nen;
+  memset(Ke, 0, sizeof(double) * nd * nd);
+  memset(Fe, 0, sizeof(double) * nd);
+  const double DT_2 = P->time_step / 2.0;
+  /* src/ripf.C:398-403: a zero "RT/r" falls back to the integer runtime parameter */
+  const double lambda_RT_r = P->lambda_RT_r ? P->lambda_RT_r : (double)P->RT_dose_total_max;
+  const double omicro_RT_r = P->omicro_RT_r ? P->omicro_RT_r : (double)P->RT_dose_total_max;
+#define KE(a, b) Ke[((a) * nen + i) * nd + (b) * nen + j]
+#define FE(a) Fe[(a) * nen + i]
+  for (int q = 0; q < nqp; q++) {
+    double HU = 0, cc = 0, fb = 0, cc_dt = 0, fb_dt = 0, RT = 0;
+    double GHU[3] = {0, 0, 0}, Gfb[3] = {0, 0, 0}, GRT[3] = {0, 0, 0};
+    for (int l = 0; l < nen; l++) { /* src/ripf.C:451-479 */
+      HU += PHI(l) * u[3 * l + 0];
+      cc += PHI(l) * u[3 * l + 1];
+      fb += PHI(l) * u[3 * l + 2];
+      cc_dt += PHI(l) * aux[3 * l + 0];
+      fb_dt += PHI(l) * aux[3 * l + 1];
+      RT += PHI(l) * aux[3 * l + 2];
+      for (int d = 0; d < 3; d++) {
+        GHU[d] += DPHI(l, d) * u[3 * l + 0];
+        Gfb[d] += DPHI(l, d) * u[3 * l + 2];
+        GRT[d] += DPHI(l, d) * aux[3 * l + 2];
+      }
+    }
+    { /* unit radiotherapy gradient, src/ripf.C:481-484 */
+      const double l2 = sqrt(GRT[0] * GRT[0] + GRT[1] * GRT[1] + GRT[2] * GRT[2]);
+      if (l2) { GRT[0] /= l2; GRT[1] /= l2; GRT[2] /= l2; }
+      else { GRT[0] = GRT[1] = GRT[2] = 0.0; }
+    }
+    /* src/ripf.C:486-496 */
+    const double kappa_RT = P->kappa * exp(-P->kappa_RT_c * RT);
+    const double delta_RT = P->delta * (1.0 - exp(-P->delta_RT_a * RT - P->delta_RT_b * pow2(RT)));
+    const double lambda_RT = P->lambda * (RT / lambda_RT_r);
+    const double omicro_RT = P->omicro * apply_lbound(0.0, 4.0 * ((RT / omicro_RT_r) - pow2(RT / omicro_RT_r)));
+    double eps_cc = 0.0, eps_fb = 0.0;
+    if (cc_dt > P->phi_tol) eps_cc = P->phi_cc_B; else if (cc_dt < -P->phi_tol) eps_cc = P->phi_cc_D;
+    if (fb_dt > P->phi_tol) eps_fb = P->phi_fb_B; else if (fb_dt < -P->phi_tol) eps_fb = P->phi_fb_D;
+    /* src/ripf.C:498-514 */
+    const double VF_total = P->VolFr_stroma + P->VolFr_parenchyma + (cc + fb);
+    double Tau = 0.0, dTau = 0.0; /* Tau__dcc == Tau__dfb */
+    if (VF_total < 1.0) {
+      Tau = pow(1.0 - VF_total, P->VolFr_exponent);
+      dTau = -P->VolFr_exponent * pow(1.0 - VF_total, P->VolFr_exponent - 1.0);
+      if (Tau < P->VolFr_min_vacant) { Tau = 0.0; dTau = 0.0; }
+    }
+    /* src/ripf.C:516-523 */
+    double Koppa = 0.0, Koppa_dcc = 0.0;
+    if (cc < 0.0) { }
+    else if (cc < 1.0) { Koppa = 4.0 * (cc - cc * cc); Koppa_dcc = 4.0 - 8.0 * cc; }
+    /* src/ripf.C:525-561 (the d/dcc and Omecro d/dHU derivatives are identically zero) */
+    double Lom = 0.0, Lom_dHU = 0.0, Lom_dcc = 0.0, Lom_dfb = 0.0;
+    double Ome = 0.0, Ome_dHU = 0.0, Ome_dcc = 0.0, Ome_dfb = 0.0;
+    if (fb < 0.0) { }
+    else if (fb < 1.0) {
+      if (HU > P->lambda_HU_r && HU < 0.0) {
+        Lom = (1.0 - pow2(fb)) * (HU / P->lambda_HU_r);
+        Lom_dHU = (1.0 - pow2(fb)) / P->lambda_HU_r;
+        Lom_dfb = -(2.0 * fb) * (HU / P->lambda_HU_r);
+      } else if (HU < P->lambda_HU_r) {
+        Lom = (1.0 - pow2(fb));
+        Lom_dfb = -(2.0 * fb);
+      }
+      if (fb <= P->omicro_fb_b) {
+        Ome = 4.0 * (P->omicro_fb_b - pow2(P->omicro_fb_b));
+      } else {
+        Ome = 4.0 * (fb - pow2(fb));
+        Ome_dfb = 4.0 - 8.0 * fb;
+      }
+    }
+    const double W = JxW[q];
+    for (int i = 0; i < nen; i++) {
+      const double pi = PHI(i);
+      const double gfb = dot_dphi(Gfb, dphi, q, nen, i), gHU = dot_dphi(GHU, dphi, q, nen, i),
+                   gRT = dot_dphi(GRT, dphi, q, nen, i);
+      /* src/ripf.C:566-594; (GRAD_HU * fb * dphi) == fb * (GRAD_HU . dphi) */
+      FE(0) += W * (HU * pi + DT_2 * (eps_cc * cc * pi + eps_fb * fb * pi + P->phi_cc * cc_dt * pi + P->phi_fb * fb_dt * pi));
+      FE(1) += W * (cc * pi + DT_2 * (kappa_RT * Tau * Koppa * pi - delta_RT * cc * pi));
+      FE(2) += W * (fb * pi + DT_2 * (lambda_RT * Tau * Lom * pi + omicro_RT * Tau * Ome * pi - P->omega * fb * pi -
+                                      P->diffusion * Tau * gfb - P->haptotaxis * Tau * (fb * gHU) -
+                                      P->radiotaxis * Tau * (fb * gRT)));
+      for (int j = 0; j < nen; j++) {
+        const double pj = PHI(j), pp = pj * pi, dd = dphi_dphi(dphi, q, nen, j, i);
+        /* src/ripf.C:599-662 */
+        KE(0, 0) += W * (pp);
+        KE(0, 1) += W * (-DT_2 * (eps_cc * pp));
+        KE(0, 2) += W * (-DT_2 * (eps_fb * pp));
+        KE(1, 1) += W * (pp - DT_2 * (kappa_RT * dTau * Koppa * pp + kappa_RT * Tau * Koppa_dcc * pp - delta_RT * pp));
+        KE(1, 2) += W * (-DT_2 * (kappa_RT * dTau * Koppa * pp));
+        KE(2, 0) += W * (-DT_2 * (lambda_RT * Tau * Lom_dHU * pp + omicro_RT * Tau * Ome_dHU * pp -
+                                  P->haptotaxis * Tau * (fb * dd)));
+        KE(2, 1) += W * (-DT_2 * (lambda_RT * dTau * Lom * pp + lambda_RT * Tau * Lom_dcc * pp +
+                                  omicro_RT * dTau * Ome * pp + omicro_RT * Tau * Ome_dcc * pp -
+                                  P->diffusion * dTau * pj * gfb - P->haptotaxis * dTau * pj * (fb * gHU) -
+                                  P->radiotaxis * dTau * pj * (fb * gRT)));
+        KE(2, 2) += W * (pp - DT_2 * (lambda_RT * dTau * Lom * pp + lambda_RT * Tau * Lom_dfb * pp +
+                                      omicro_RT * dTau * Ome * pp + omicro_RT * Tau * Ome_dfb * pp -
+                                      P->omega * pp - P->diffusion * dTau * pj * gfb - P->diffusion * Tau * dd -
+                                      P->haptotaxis * dTau * pj * (fb * gHU) - P->haptotaxis * Tau * (pj * gHU) -
+                                      P->radiotaxis * dTau * pj * (fb * gRT) - P->radiotaxis * Tau * (pj * gRT)));
+      }
+    }
+  }
+#undef KE
+#undef FE
+}
+
+/* ------------------------------------------------------------------------------------------
+ * HCC integrand                                                  src/coupled_hcc.C:496-640
+ * u: [nen][3] (l,c,n).  Reference quirks reproduced verbatim:
+ *  - "capacity" pp term also in blocks [0][1], [0][2], [1][0]          (:577-598)
+ *  - the d/dn block of the c-equation is added into [1][1] a second time, [1][2] never (:611-619)
+ *  - GRAD_sigma is identically zero                                     (:508)
+ * ------------------------------------------------------------------------------------------ */
+void oracle_hcc_element(int nen, int nqp, const double* phi, const double* dphi,
+                        const double* JxW, const double* u, const rdc_hcc_params* P, double* Ke,
+                        double* Fe) {
+  const int nd = 3 * nen;
+  memset(Ke, 0, sizeof(double) * nd * nd);
+  memset(Fe, 0, sizeof(double) * nd);
+  const double DT_2 = P->time_step / 2.0;
+  const double Lambda_k = P->cells_min_capacity, Kappa_k = P->cells_max_capacity,
+               ek = P->cells_max_capacity_exponent;
+  const double prod_l = P->produce_l, prod_c = P->produce_c;
+  const double nec_l = P->necrosis_l / Kappa_k, nec_c = P->necrosis_c / Kappa_k;
+#define KE(a, b) Ke[((a) * nen + i) * nd + (b) * nen + j]
+#define FE(a) Fe[(a) * nen + i]
+  for (int q = 0; q < nqp; q++) {
+    double l_ = 0, c_ = 0, n_ = 0, Gc[3] = {0, 0, 0};
+    for (int k = 0; k < nen; k++) { /* :498-506 */
+      l_ += PHI(k) * u[3 * k + 0];
+      c_ += PHI(k) * u[3 * k + 1];
+      n_ += PHI(k) * u[3 * k + 2];
+      for (int d = 0; d < 3; d++) Gc[d] += DPHI(k, d) * u[3 * k + 1];
+    }
+    const double Gs[3] = {0.0, 0.0, 0.0}; /* :508 */
+    double Tau, dT;                       /* :510-532 */
+    {
+      const double Te = (l_ + c_ + n_) / Kappa_k;
+      if (Te <= 0.0) { Tau = 1.0; dT = 0.0; }
+      else if (Te >= 1.0) { Tau = 0.0; dT = 0.0; }
+      else { Tau = pow(1.0 - Te, ek); dT = (-ek / Kappa_k) * pow(1.0 - Te, ek - 1.0); }
+    }
+    const double dif_c = (c_ > Lambda_k ? P->diffuse_c : 0.0), mec_c = (c_ > Lambda_k ? P->mechano_c : 0.0);
+    const double W = JxW[q];
+    for (int i = 0; i < nen; i++) {
+      const double pi = PHI(i), gc = dot_dphi(Gc, dphi, q, nen, i), gs = dot_dphi(Gs, dphi, q, nen, i);
+      /* :540-564 */
+      FE(0) += W * (l_ * pi + DT_2 * (prod_l * Tau * l_ * pi - nec_l * l_ * n_ * pi));
+      FE(1) += W * (c_ * pi + DT_2 * (prod_c * Tau * c_ * pi - nec_c * c_ * n_ * pi - dif_c * Tau * gc -
+                                      mec_c * Tau * c_ * gs));
+      FE(2) += W * (n_ * pi + DT_2 * (nec_l * l_ * n_ * pi + nec_c * c_ * n_ * pi));
+      for (int j = 0; j < nen; j++) {
+        const double pj = PHI(j), pp = pj * pi, dd = dphi_dphi(dphi, q, nen, j, i);
+        /* :569-637 */
+        KE(0, 0) += W * (pp - DT_2 * (prod_l * Tau * pp + prod_l * dT * pj * l_ * pi - nec_l * pj * n_ * pi));
+        KE(0, 1) += W * (pp - DT_2 * (prod_l * dT * pj * l_ * pi));
+        KE(0, 2) += W * (pp - DT_2 * (prod_l * dT * pj * l_ * pi - nec_l * l_ * pp));
+        KE(1, 0) += W * (pp - DT_2 * (prod_c * dT * pj * c_ * pi - dif_c * dT * pj * gc - mec_c * dT * pj * c_ * gs));
+        KE(1, 1) += W * (pp - DT_2 * (prod_c * Tau * pp + prod_c * dT * pj * c_ * pi - nec_c * pj * n_ * pi -
+                                      dif_c * dT * pj * gc - dif_c * Tau * dd - mec_c * dT * pj * c_ * gs -
+                                      mec_c * Tau * pj * gs));
+        KE(1, 1) += W * (pp - DT_2 * (prod_c * dT * pj * c_ * pi - nec_c * c_ * pp - dif_c * dT * pj * gc -
+                                      mec_c * dT * pj * c_ * gs));
+        KE(2, 0) += W * (-DT_2 * (nec_l * pj * n_ * pi));
+        KE(2, 1) += W * (-DT_2 * (nec_c * pj * n_ * pi));
+        KE(2, 2) += W * (pp - DT_2 * (nec_l * l_ * pp + nec_c * c_ * pp));
+      }
+    }
+  }
+#undef KE
+#undef FE
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Hyperelastic constitutive law      src/hyperelastic.h:25-87, src/hyperlastic_inline.h:3-189
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  double F[3][3], Fe[3][3], Fp[3][3], A[3];
+  double sigma[3][3];
+  double C[6][6];
+} hyper_state;
+
+static void mat3_mul(const double a[3][3], const double b[3][3], double r[3][3]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j];
+}
+
+/* src/hyperlastic_inline.h:18-189 */
+static void hyper_calculate_stress(hyper_state* S, double Young, double Poisson, double FibreStiffness,
+                                   int tangent) {
+  const double mu = 0.5 * Young / (1.0 + Poisson);
+  const double lambda = Young * Poisson / ((1.0 + Poisson) * (1.0 - 2.0 * Poisson));
+  const double koppa = FibreStiffness / 2.0;
+  double FeT[3][3], Ce[3][3], CeINV[3][3], FpINV[3][3], CeCe[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) FeT[i][j] = S->Fe[j][i];
+  mat3_mul(FeT, S->Fe, Ce);
+  inv3(Ce, CeINV);
+  inv3(S->Fp, FpINV);
+  static const double delta[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  const double I1 = Ce[0][0] + Ce[1][1] + Ce[2][2];
+  mat3_mul(Ce, Ce, CeCe);
+  const double I2 = 0.5 * (pow2(I1) - (CeCe[0][0] + CeCe[1][1] + CeCe[2][2]));
+  (void)I2;
+  const double Je = det3(S->Fe);
+  const double J_recip = 1.0 / det3(S->F);
+  const double dWdI1 = (mu / 2.0), dWdI2 = 0.0;
+  const double dWdJe = (-mu / Je) + (lambda / 2.0 * Je - lambda / 2.0 / Je);
+  const double dWdI4 = (-koppa);
+  const double d2WdI1dI1 = 0.0, d2WdI2dI2 = 0.0, d2WdI4dI4 = 0.0;
+  const double d2WdJedJe = (mu / Je / Je) + (lambda / 2.0 + lambda / 2.0 / Je / Je);
+  double dI1[3][3], dI2[3][3], dJe[3][3], dI4[3][3];
+  static double d2I2[3][3][3][3], d2Je[3][3][3][3]; /* not re-entrant: oracle is single-threaded */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      dI1[i][j] = delta[i][j];
+      dI2[i][j] = delta[i][j] * I1 - Ce[i][j];
+      dJe[i][j] = 0.5 * Je * CeINV[i][j];
+      dI4[i][j] = S->A[i] * S->A[j];
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          d2I2[i][j][k][l] = delta[i][j] * delta[k][l] - 0.5 * delta[i][k] * delta[j][l] - 0.5 * delta[i][l] * delta[j][k];
+          d2Je[i][j][k][l] = 0.25 * Je * CeINV[i][j] * CeINV[k][l] - 0.25 * Je * CeINV[i][k] * CeINV[j][l] -
+                             0.25 * Je * CeINV[i][l] * CeINV[j][k];
+        }
+    }
+  double S2pk[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      S2pk[i][j] = 2.0 * dWdI1 * dI1[i][j] + 2.0 * dWdI2 * dI2[i][j] + 2.0 * dWdJe * dJe[i][j] + 2.0 * dWdI4 * dI4[i][j];
+  /* push-forward with the TOTAL F and 1/det F (App. D.6) */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int I = 0; I < 3; I++)
+        for (int J = 0; J < 3; J++) s += S->F[i][I] * S->F[j][J] * S2pk[I][J];
+      S->sigma[i][j] = s * J_recip;
+    }
+  if (!tangent) return;
+  static double dSdCe[3][3][3][3], dCedC[3][3][3][3], dSdC[3][3][3][3], tsm[3][3][3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          dSdCe[i][j][k][l] = 4.0 * dWdI2 * d2I2[i][j][k][l] + 4.0 * dWdJe * d2Je[i][j][k][l] +
+                              4.0 * d2WdI1dI1 * dI1[i][j] * dI1[k][l] + 4.0 * d2WdI2dI2 * dI2[i][j] * dI2[k][l] +
+                              4.0 * d2WdJedJe * dJe[i][j] * dJe[k][l] + 4.0 * d2WdI4dI4 * dI4[i][j] * dI4[k][l];
+          dCedC[i][j][k][l] = 0.5 * FpINV[k][i] * FpINV[j][l] + 0.5 * FpINV[l][i] * FpINV[k][j];
+        }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          double s = 0.0;
+          for (int m = 0; m < 3; m++)
+            for (int n = 0; n < 3; n++) s += dSdCe[i][j][m][n] * dCedC[m][n][k][l];
+          dSdC[i][j][k][l] = s;
+        }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < 3; k++)
+        for (int l = 0; l < 3; l++) {
+          double s = 0.0;
+          for (int I = 0; I < 3; I++)
+            for (int J = 0; J < 3; J++)
+              for (int K = 0; K < 3; K++)
+                for (int L = 0; L < 3; L++)
+                  s += S->F[i][I] * S->F[j][J] * S->F[k][K] * S->F[l][L] * dSdC[I][J][K][L];
+          tsm[i][j][k][l] = s * J_recip;
+        }
+  /* Voigt order (00,11,22,01,12,02), src/hyperelastic.h:15-20, src/hyperlastic_inline.h:153-188 */
+  static const int V[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {1, 2}, {0, 2}};
+  for (int p = 0; p < 6; p++)
+    for (int q = 0; q < 6; q++) S->C[p][q] = tsm[V[p][0]][V[p][1]][V[q][0]][V[q][1]];
+}
+
+/* src/hyperelastic.h:25-49.  gradX[d][c] = d X_d / d x_c */
+static void hyper_initialize(hyper_state* S, const double gradX[3][3], const double lam[3],
+                             const double f[3], double Young, double Poisson, double K, int tangent) {
+  inv3(gradX, S->F);
+  memset(S->Fp, 0, sizeof(S->Fp));
+  for (int l = 0; l < 3; l++) S->Fp[l][l] = lam[l];
+  double FpINV[3][3];
+  inv3(S->Fp, FpINV);
+  mat3_mul(S->F, FpINV, S->Fe);
+  if (K > 0.0) {
+    const double nrm = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    for (int d = 0; d < 3; d++) S->A[d] = f[d] / nrm;
+  } else {
+    S->A[0] = S->A[1] = S->A[2] = 0.0;
+  }
+  hyper_calculate_stress(S, Young, Poisson, K, tangent);
+}
+
+/* src/hyperlastic_inline.h:3-15 */
+static void hyper_B(const double g[3], double B[3][6]) {
+  memset(B, 0, sizeof(double) * 18);
+  B[0][0] = g[0]; B[1][1] = g[1]; B[2][2] = g[2];
+  B[0][3] = g[1]; B[1][3] = g[0];
+  B[1][4] = g[2]; B[2][4] = g[1];
+  B[0][5] = g[2]; B[2][5] = g[0];
+}
+
+/* test hook: sigma and Voigt tangent for given F-inverse (gradX), growth stretches, fibre */
+void oracle_hyperelastic_point(const double* gradX9, const double* lambda3, const double* fibre3,
+                               double Young, double Poisson, double K, double* sigma9, double* C36) {
+  hyper_state S;
+  double g[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) g[i][j] = gradX9[3 * i + j];
+  hyper_initialize(&S, g, lambda3, fibre3, Young, Poisson, K, 1);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) sigma9[3 * i + j] = S.sigma[i][j];
+  for (int p = 0; p < 6; p++) for (int q = 0; q < 6; q++) C36[6 * p + q] = S.C[p][q];
+}
+
+/* SolidSystem::element_time_derivative                          src/solid_system.C:146-271
+ * phi/dphi/JxW evaluated on the CURRENT element; Xu: undeformed coords [nen][3];
+ * Re: [3 nen] var-major; Je: [3nen][3nen] var-major blocks (ii,jj)(i,j). */
+void oracle_solid_element(int nen, int nqp, const double* dphi, const double* JxW, const double* Xu,
+                          const double* fibre3, const rdc_solid_material* M, double pseudo_time,
+                          int request_jacobian, int use_symmetry, double* Je, double* Re) {
+  const int nd = 3 * nen;
+  memset(Je, 0, sizeof(double) * nd * nd);
+  memset(Re, 0, sizeof(double) * nd);
+  hyper_state S;
+  for (int q = 0; q < nqp; q++) {
+    double gradX[3][3] = {{0}}; /* :221-229 */
+    for (int d = 0; d < 3; d++)
+      for (int l = 0; l < nen; l++)
+        for (int c = 0; c < 3; c++) gradX[d][c] += DPHI(l, c) * Xu[3 * l + d];
+    double lam[3]; /* :232-234 */
+    for (int d = 0; d < 3; d++) lam[d] = 1.0 + pseudo_time * M->rate[d];
+    hyper_initialize(&S, gradX, lam, fibre3, M->Young, M->Poisson, M->FibreStiffness, request_jacobian);
+    const double SV[6] = {S.sigma[0][0], S.sigma[1][1], S.sigma[2][2], S.sigma[0][1], S.sigma[1][2], S.sigma[0][2]};
+    for (int i = 0; i < nen; i++) {
+      double Bi[3][6], gi[3] = {DPHI(i, 0), DPHI(i, 1), DPHI(i, 2)};
+      hyper_B(gi, Bi);
+      for (int ii = 0; ii < 3; ii++) { /* get_residual, src/hyperelastic.h:52-66 */
+        double r = 0.0;
+        for (int p = 0; p < 6; p++) r += Bi[ii][p] * SV[p];
+        Re[ii * nen + i] += r * JxW[q];
+      }
+      if (!request_jacobian) continue;
+      for (int j = (use_symmetry ? i : 0); j < nen; j++) { /* :252-265 */
+        double Bj[3][6], gj[3] = {DPHI(j, 0), DPHI(j, 1), DPHI(j, 2)}, D[3][3] = {{0}};
+        hyper_B(gj, Bj);
+        /* get_linearized_stiffness, src/hyperelastic.h:68-87 */
+        double G = 0.0;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) G += gi[r] * S.sigma[r][c] * gj[c];
+        for (int n = 0; n < 3; n++) D[n][n] += G;
+        double BC[3][6];
+        for (int r = 0; r < 3; r++)
+          for (int p = 0; p < 6; p++) {
+            double s = 0.0;
+            for (int t = 0; t < 6; t++) s += Bi[r][t] * S.C[t][p];
+            BC[r][p] = s;
+          }
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) {
+            double s = 0.0;
+            for (int p = 0; p < 6; p++) s += BC[r][p] * Bj[c][p];
+            D[r][c] += s;
+          }
+        for (int ii = 0; ii < 3; ii++)
+          for (int jj = 0; jj < 3; jj++) {
+            Je[(ii * nen + i) * nd + jj * nen + j] += D[ii][jj] * JxW[q];
+            if (use_symmetry && i != j) Je[(ii * nen + j) * nd + jj * nen + i] += D[jj][ii] * JxW[q];
+          }
+      }
+    }
+  }
+}
+
+/* side tables (libMesh Tet4::side_nodes_map / Hex8::side_nodes_map) */
+static const int TET_SIDE[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {2, 0, 3}};
+static const int HEX_SIDE[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
+
+/* SolidSystem::side_time_derivative                              src/solid_system.C:273-371
+ * x: current coords [nen][3], Xu: undeformed; disp: prescribed displacement (NaN = free);
+ * ADDS into Je/Re.  Side rule: QGauss(2, THIRD) on TRI3 (4 pts) / QUAD4 (2x2) [App. B.2]. */
+void oracle_solid_side(int nen, int side, const double* x, const double* Xu, const double* disp3,
+                       double pseudo_time, double penalty, int request_jacobian, double* Je, double* Re) {
+  const int nd = 3 * nen;
+  const double ratio = pseudo_time * 1.000001; /* :291-292 */
+  const int nsn = (nen == 4) ? 3 : 4;
+  const int* sn = (nen == 4) ? TET_SIDE[side] : HEX_SIDE[side];
+  const int nq = 4;
+  double qxi[4][2], qw[4];
+  if (nen == 4) {
+    static const double P[4][2] = {{1.0 / 3.0, 1.0 / 3.0}, {0.2, 0.6}, {0.2, 0.2}, {0.6, 0.2}};
+    static const double Wt[4] = {-27.0 / 96.0, 25.0 / 96.0, 25.0 / 96.0, 25.0 / 96.0};
+    for (int q = 0; q < 4; q++) { qxi[q][0] = P[q][0]; qxi[q][1] = P[q][1]; qw[q] = Wt[q]; }
+  } else {
+    const double g = 0.57735026918962576451;
+    for (int q = 0; q < 4; q++) { qxi[q][0] = (q & 1) ? g : -g; qxi[q][1] = (q & 2) ? g : -g; qw[q] = 1.0; }
+  }
+  for (int q = 0; q < nq; q++) {
+    double N[4], dN[4][2];
+    if (nsn == 3) {
+      N[0] = 1.0 - qxi[q][0] - qxi[q][1]; N[1] = qxi[q][0]; N[2] = qxi[q][1];
+      dN[0][0] = -1; dN[0][1] = -1; dN[1][0] = 1; dN[1][1] = 0; dN[2][0] = 0; dN[2][1] = 1;
+    } else {
+      static const double Cq[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+      for (int n = 0; n < 4; n++) {
+        N[n] = 0.25 * (1 + Cq[n][0] * qxi[q][0]) * (1 + Cq[n][1] * qxi[q][1]);
+        dN[n][0] = 0.25 * Cq[n][0] * (1 + Cq[n][1] * qxi[q][1]);
+        dN[n][1] = 0.25 * (1 + Cq[n][0] * qxi[q][0]) * Cq[n][1];
+      }
+    }
+    double t1[3] = {0, 0, 0}, t2[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, org[3] = {0, 0, 0};
+    for (int n = 0; n < nsn; n++)
+      for (int d = 0; d < 3; d++) {
+        t1[d] += x[3 * sn[n] + d] * dN[n][0];
+        t2[d] += x[3 * sn[n] + d] * dN[n][1];
+        cur[d] += x[3 * sn[n] + d] * N[n];   /* coords[qp], :338 */
+        org[d] += Xu[3 * sn[n] + d] * N[n];  /* orig_point, :326-334 */
+      }
+    const double cx = t1[1] * t2[2] - t1[2] * t2[1], cy = t1[2] * t2[0] - t1[0] * t2[2], cz = t1[0] * t2[1] - t1[1] * t2[0];
+    const double W = sqrt(cx * cx + cy * cy + cz * cz) * qw[q];
+    double diff[3];
+    for (int d = 0; d < 3; d++) diff[d] = cur[d] - org[d] - disp3[d] * ratio; /* :337-339 */
+    for (int a = 0; a < nsn; a++) {
+      const int i = sn[a];
+      for (int di = 0; di < 3; di++) {
+        if (isnan(diff[di])) continue;
+        Re[di * nen + i] += W * N[a] * diff[di] * penalty; /* :346-351 */
+      }
+      if (!request_jacobian) continue;
+      for (int b = 0; b < nsn; b++) {
+        const int j = sn[b];
+        for (int dj = 0; dj < 3; dj++) {
+          if (isnan(diff[dj])) continue;
+          Je[(dj * nen + i) * nd + dj * nen + j] += W * N[a] * N[b] * penalty; /* :358-362 */
+        }
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sparsity pattern (what es.init() builds) and global scatter (add_matrix / add_vector)
+ * ------------------------------------------------------------------------------------------ */
+static int cmp_i64(const void* a, const void* b) {
+  const int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+  return (x > y) - (x < y);
+}
+
+/* Node-graph pattern for the owned rows.  Two-call protocol: with bcol == NULL only bptr and the
+ * return value (number of node blocks) are produced. */
+int64_t oracle_build_node_pattern(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
+                                  const uint32_t* conn, int64_t* bptr /*[n_owned+1]*/, int32_t* bcol) {
+  int64_t* cnt = (int64_t*)calloc((size_t)n_node + 1, sizeof(int64_t));
+  for (int64_t e = 0; e < n_elem; e++)
+    for (int i = 0; i < nen; i++) cnt[conn[e * nen + i] + 1]++;
+  for (int64_t n = 0; n < n_node; n++) cnt[n + 1] += cnt[n];
+  int64_t* inc = (int64_t*)malloc(sizeof(int64_t) * (size_t)cnt[n_node]);
+  int64_t* fill = (int64_t*)calloc((size_t)n_node, sizeof(int64_t));
+  for (int64_t e = 0; e < n_elem; e++)
+    for (int i = 0; i < nen; i++) {
+      const int64_t n = conn[e * nen + i];
+      inc[cnt[n] + fill[n]++] = e;
+    }
+  int64_t total = 0, cap = 64;
+  int64_t* tmp = (int64_t*)malloc(sizeof(int64_t) * (size_t)cap);
+  bptr[0] = 0;
+  for (int64_t n = 0; n < n_owned; n++) {
+    const int64_t ne = cnt[n + 1] - cnt[n];
+    if (ne * nen + 1 > cap) { cap = 2 * (ne * nen + 1); tmp = (int64_t*)realloc(tmp, sizeof(int64_t) * (size_t)cap); }
+    int64_t m = 0;
+    tmp[m++] = n; /* diagonal always present */
+    for (int64_t k = 0; k < ne; k++)
+      for (int i = 0; i < nen; i++) tmp[m++] = conn[inc[cnt[n] + k] * nen + i];
+    qsort(tmp, (size_t)m, sizeof(int64_t), cmp_i64);
+    int64_t u = 0;
+    for (int64_t k = 0; k < m; k++)
+      if (k == 0 || tmp[k] != tmp[k - 1]) {
+        if (bcol) bcol[total + u] = (int32_t)tmp[k];
+        u++;
+      }
+    total += u;
+    bptr[n + 1] = total;
+  }
+  free(tmp); free(fill); free(inc); free(cnt);
+  return total;
+}
+
+/* scalar CSR (AIJ) from the node pattern: row = node*nvar+a, cols = nodecol*nvar+b ascending */
+void oracle_expand_pattern(int nvar, int64_t n_owned, const int64_t* bptr, const int32_t* bcol,
+                           int64_t* row_ptr, int32_t* col_idx) {
+  int64_t p = 0;
+  row_ptr[0] = 0;
+  for (int64_t n = 0; n < n_owned; n++)
+    for (int a = 0; a < nvar; a++) {
+      for (int64_t k = bptr[n]; k < bptr[n + 1]; k++)
+        for (int b = 0; b < nvar; b++) col_idx[p++] = bcol[k] * nvar + b;
+      row_ptr[n * nvar + a + 1] = p;
+    }
+}
+
+/* MatSetValues(ADD_VALUES)-like insertion: binary search of the column in the sorted row */
+static inline void csr_add(const int64_t* row_ptr, const int32_t* col_idx, double* val, int64_t row,
+                           int32_t col, double v) {
+  int64_t lo = row_ptr[row], hi = row_ptr[row + 1] - 1;
+  while (lo <= hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    const int32_t c = col_idx[mid];
+    if (c == col) { val[mid] += v; return; }
+    if (c < col) lo = mid + 1; else hi = mid - 1;
+  }
+  abort(); /* pattern violation: must never happen */
+}
+
+/* Whole-mesh assembly = the reference callback.  model: 0 PIHNA, 1 RIPF, 2 HCC, 3 SOLID.
+ * Elements [e_begin, e_end) only (lets the CPU baseline time a bounded sample). */
+int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, int64_t n_owned,
+                    const uint32_t* conn, const double* xyz, int nvar, const double* u_old,
+                    const double* aux_nodal, const double* xyz_undeformed, const double* elem_fibre,
+                    const int32_t* elem_material, const rdc_solid_material* materials,
+                    const void* params, int request_jacobian, const int64_t* row_ptr,
+                    const int32_t* col_idx, double* val, double* rhs) {
+  const int nen = elem_type, nqp = oracle_nqp(elem_type);
+  if (nqp < 0) return 1;
+  const int nd = nvar * nen;
+  double X[8 * 3], U[8 * 5], A[8 * 3], XU[8 * 3], phi[8 * 8], dphi[8 * 8 * 3], JxW[8];
+  double* Ke = (double*)malloc(sizeof(double) * nd * nd);
+  double* Fe = (double*)malloc(sizeof(double) * nd);
+  for (int64_t e = e_begin; e < e_end; e++) {
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++) {
+      for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+      if (u_old) for (int a = 0; a < nvar; a++) U[nvar * i + a] = u_old[(int64_t)c[i] * nvar + a];
+      if (aux_nodal) for (int a = 0; a < 3; a++) A[3 * i + a] = aux_nodal[(int64_t)c[i] * 3 + a];
+      if (xyz_undeformed) for (int d = 0; d < 3; d++) XU[3 * i + d] = xyz_undeformed[3 * (int64_t)c[i] + d];
+    }
+    oracle_fe_reinit(elem_type, X, phi, dphi, JxW);
+    switch (model) {
+      case 0: oracle_pihna_element(nen, nqp, phi, dphi, JxW, U, (const rdc_pihna_params*)params, Ke, Fe); break;
+      case 1: oracle_ripf_element(nen, nqp, phi, dphi, JxW, U, A, (const rdc_ripf_params*)params, Ke, Fe); break;
+      case 2: oracle_hcc_element(nen, nqp, phi, dphi, JxW, U, (const rdc_hcc_params*)params, Ke, Fe); break;
+      case 3: {
+        const rdc_solid_params* sp = (const rdc_solid_params*)params;
+        oracle_solid_element(nen, nqp, dphi, JxW, XU, elem_fibre + 3 * e, &materials[elem_material[e]],
+                             sp->pseudo_time, request_jacobian, sp->use_symmetry, Ke, Fe);
+      } break;
+      default: free(Ke); free(Fe); return 2;
+    }
+    /* add_matrix / add_vector, src/pihna.C:754-755 (constraints are the identity here) */
+    for (int a = 0; a < nvar; a++)
+      for (int i = 0; i < nen; i++) {
+        if ((int64_t)c[i] >= n_owned) continue; /* row owned elsewhere */
+        const int64_t row = (int64_t)c[i] * nvar + a;
+        rhs[row] += Fe[a * nen + i];
+        if (model == 3 && !request_jacobian) continue;
+        for (int b = 0; b < nvar; b++)
+          for (int j = 0; j < nen; j++)
+            csr_add(row_ptr, col_idx, val, row, (int32_t)(c[j] * nvar + b), Ke[(a * nen + i) * nd + b * nen + j]);
+      }
+  }
+  free(Ke); free(Fe);
+  return 0;
+}
+
+/* boundary sides of the solid system, added after the element loop (FEMSystem::assembly order) */
+int oracle_assemble_solid_sides(int elem_type, int64_t n_sides, const int64_t* side_elem,
+                                const int32_t* side_id, const double* side_disp, int64_t n_owned,
+                                const uint32_t* conn, const double* xyz, const double* xyz_undeformed,
+                                const rdc_solid_params* sp, int request_jacobian, const int64_t* row_ptr,
+                                const int32_t* col_idx, double* val, double* rhs) {
+  const int nen = elem_type, nd = 3 * nen;
+  double X[24], XU[24];
+  double* Ke = (double*)malloc(sizeof(double) * nd * nd);
+  double* Fe = (double*)malloc(sizeof(double) * nd);
+  for (int64_t s = 0; s < n_sides; s++) {
+    const int64_t e = side_elem[s];
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++)
+      for (int d = 0; d < 3; d++) {
+        X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+        XU[3 * i + d] = xyz_undeformed[3 * (int64_t)c[i] + d];
+      }
+    memset(Ke, 0, sizeof(double) * nd * nd);
+    memset(Fe, 0, sizeof(double) * nd);
+    oracle_solid_side(nen, side_id[s], X, XU, side_disp + 3 * s, sp->pseudo_time, sp->displacement_penalty,
+                      request_jacobian, Ke, Fe);
+    for (int a = 0; a < 3; a++)
+      for (int i = 0; i < nen; i++) {
+        if ((int64_t)c[i] >= n_owned) continue;
+        const int64_t row = (int64_t)c[i] * 3 + a;
+        rhs[row] += Fe[a * nen + i];
+        if (!request_jacobian) continue;
+        for (int b = 0; b < 3; b++)
+          for (int j = 0; j < nen; j++) {
+            const double v = Ke[(a * nen + i) * nd + b * nen + j];
+            if (v != 0.0) csr_add(row_ptr, col_idx, val, row, (int32_t)(c[j] * 3 + b), v);
+          }
+      }
+  }
+  free(Ke); free(Fe);
+  return 0;
+}
+
+/* check_solution negativity clamp, src/pihna.C:785-790 */
+void oracle_clamp_nonnegative(double* u, int64_t n) {
+  for (int64_t i = 0; i < n; i++) if (u[i] < 0.0) u[i] = 0.0;
+}

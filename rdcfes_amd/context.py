@@ -1,0 +1,192 @@
+"""Thin object wrapper over the C-ABI (include/rdc_assembly.h); one instance == one rdc_ctx."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .params import HccParams, PihnaParams, RipfParams, SolidMaterial, SolidParams
+
+TET4, HEX8 = 4, 8
+SCATTER_AUTO, SCATTER_COLOURED, SCATTER_ROWGATHER = 0, 1, 2
+FIELD_OLD_SOLUTION, FIELD_AUX_NODAL, FIELD_UNDEFORMED_XYZ, FIELD_ELEM_FIBRE = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_GENERIC = 0, 1
+
+
+class RdcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rdc error {code}: {msg}")
+        self.code = code
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class AssemblyContext:
+    """Owns one rdc_ctx (one GPU, one mesh partition, one system)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.rdc_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RdcError(rc, self._lib.rdc_last_error(None).decode())
+        self._h = h
+        self.n_elem = self.n_node = self.n_owned = 0
+        self.nvar = 0
+
+    # -- plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise RdcError(rc, self._lib.rdc_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rdc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, hip_stream_ptr):
+        self._ck(self._lib.rdc_set_stream(self._h, C.c_void_p(int(hip_stream_ptr) if hip_stream_ptr else None)))
+
+    def synchronize(self):
+        self._ck(self._lib.rdc_synchronize(self._h))
+
+    def set_scatter(self, strategy):
+        self._ck(self._lib.rdc_set_scatter(self._h, int(strategy)))
+
+    def set_kernel_variant(self, variant):
+        self._ck(self._lib.rdc_set_kernel_variant(self._h, int(variant)))
+
+    def get_scatter(self):
+        s = C.c_int()
+        self._ck(self._lib.rdc_get_scatter(self._h, C.byref(s)))
+        return s.value
+
+    # -- mesh
+    def mesh_upload(self, elem_type, conn, xyz, nvar, n_owned=None):
+        conn = np.ascontiguousarray(conn, dtype=np.uint32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        if conn.ndim != 2 or conn.shape[1] != elem_type:
+            raise ValueError("conn must be [n_elem][elem_type]")
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise ValueError("xyz must be [n_node][3]")
+        n_owned = xyz.shape[0] if n_owned is None else int(n_owned)
+        self._ck(self._lib.rdc_mesh_upload(self._h, int(elem_type), conn.shape[0], xyz.shape[0], n_owned,
+                                           conn.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(xyz), int(nvar)))
+        self.elem_type, self.n_elem, self.n_node, self.n_owned, self.nvar = elem_type, conn.shape[0], xyz.shape[0], n_owned, nvar
+
+    def mesh_update_coords(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        if xyz.shape != (self.n_node, 3):
+            raise ValueError("xyz shape mismatch")
+        self._ck(self._lib.rdc_mesh_update_coords(self._h, _dp(xyz)))
+
+    def n_colours(self):
+        nc = C.c_int()
+        self._ck(self._lib.rdc_mesh_dims(self._h, None, None, None, None, None, C.byref(nc)))
+        return nc.value
+
+    def colours(self):
+        out = np.empty(self.n_elem, dtype=np.int32)
+        self._ck(self._lib.rdc_mesh_colours_download(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def csr_dims(self):
+        r, z = C.c_int64(), C.c_int64()
+        self._ck(self._lib.rdc_csr_dims(self._h, C.byref(r), C.byref(z)))
+        return r.value, z.value
+
+    def csr_pattern(self):
+        n_rows, nnz = self.csr_dims()
+        row_ptr = np.empty(n_rows + 1, dtype=np.int64)
+        col = np.empty(nnz, dtype=np.int32)
+        self._ck(self._lib.rdc_csr_pattern_download(self._h, row_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                    col.ctypes.data_as(C.POINTER(C.c_int32))))
+        return row_ptr, col
+
+    # -- fields
+    def field_upload(self, field, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self._ck(self._lib.rdc_field_upload(self._h, int(field), _dp(arr), arr.size))
+
+    def field_download(self, field, count):
+        out = np.empty(int(count), dtype=np.float64)
+        self._ck(self._lib.rdc_field_download(self._h, int(field), _dp(out), out.size))
+        return out
+
+    def field_device_ptr(self, field, count):
+        p = C.c_void_p()
+        self._ck(self._lib.rdc_field_device_ptr(self._h, int(field), int(count), C.byref(p)))
+        return p.value
+
+    def field_bind_device(self, field, dptr, count):
+        self._ck(self._lib.rdc_field_bind_device(self._h, int(field), C.c_void_p(int(dptr)), int(count)))
+
+    def clamp_nonnegative(self, field):
+        self._ck(self._lib.rdc_clamp_nonnegative(self._h, int(field)))
+
+    # -- solid set-up
+    def solid_set_materials(self, elem_material, materials):
+        em = np.ascontiguousarray(elem_material, dtype=np.int32)
+        if em.shape != (self.n_elem,):
+            raise ValueError("elem_material must have one entry per element")
+        arr = (SolidMaterial * len(materials))(*materials)
+        self._ck(self._lib.rdc_solid_set_materials(self._h, em.ctypes.data_as(C.POINTER(C.c_int32)), len(materials), arr))
+
+    def solid_set_sides(self, side_elem, side_id, side_disp):
+        se = np.ascontiguousarray(side_elem, dtype=np.int64)
+        si = np.ascontiguousarray(side_id, dtype=np.int32)
+        sd = np.ascontiguousarray(side_disp, dtype=np.float64).reshape(-1, 3)
+        if not (se.shape[0] == si.shape[0] == sd.shape[0]):
+            raise ValueError("side arrays must have equal length")
+        self._ck(self._lib.rdc_solid_set_sides(self._h, se.shape[0], se.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               si.ctypes.data_as(C.POINTER(C.c_int32)), _dp(sd)))
+
+    # -- the hot path
+    def assemble_pihna(self, p: PihnaParams):
+        self._ck(self._lib.rdc_assemble_pihna(self._h, C.byref(p)))
+
+    def assemble_ripf(self, p: RipfParams):
+        self._ck(self._lib.rdc_assemble_ripf(self._h, C.byref(p)))
+
+    def assemble_hcc(self, p: HccParams):
+        self._ck(self._lib.rdc_assemble_hcc(self._h, C.byref(p)))
+
+    def solid_assemble(self, p: SolidParams, request_jacobian=True):
+        self._ck(self._lib.rdc_solid_assemble(self._h, C.byref(p), 1 if request_jacobian else 0))
+
+    # -- results
+    def csr_values_device_ptr(self):
+        v, r = C.c_void_p(), C.c_void_p()
+        self._ck(self._lib.rdc_csr_values_device_ptr(self._h, C.byref(v), C.byref(r)))
+        return v.value, r.value
+
+    def csr_download(self, want_val=True, want_rhs=True):
+        n_rows, nnz = self.csr_dims()
+        val = np.empty(nnz, dtype=np.float64) if want_val else None
+        rhs = np.empty(n_rows, dtype=np.float64) if want_rhs else None
+        self._ck(self._lib.rdc_csr_download(self._h, _dp(val) if want_val else None, _dp(rhs) if want_rhs else None))
+        return val, rhs
+
+    # -- instrumentation
+    def timing_enable(self, on=True):
+        self._ck(self._lib.rdc_timing_enable(self._h, 1 if on else 0))
+
+    def timing_last_ms(self):
+        ms = C.c_float()
+        self._ck(self._lib.rdc_timing_last_ms(self._h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,568 @@
+// rdc_capi.hip — implementation of the C-ABI declared in include/rdc_assembly.h.
+// No CPU fallback lives here: every assemble call launches HIP kernels or fails.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "rdc_internal.h"
+#include "rdc_solid.h"
+
+using namespace rdc;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool owned = true;
+};
+
+thread_local char g_create_error[512] = "";
+
+}  // namespace
+
+struct rdc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = "";
+  bool have_mesh = false;
+  int strategy = RDC_SCATTER_AUTO;
+  int variant = RDC_VARIANT_AUTO;
+  HostPrep prep;
+  // device mesh data
+  DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
+      wg_node_ptr;
+  DevBuf val, rhs, packed;
+  DevBuf field[RDC_FIELD_COUNT];
+  int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
+  // solid
+  DevBuf elem_material, materials, side_elem, side_id, side_disp;
+  int32_t n_materials = 0;
+  int64_t n_sides = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  size_t max_lds = 64 * 1024;
+};
+
+namespace {
+
+int fail(rdc_ctx* c, int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (c) vsnprintf(c->err, sizeof(c->err), fmt, ap);
+  else vsnprintf(g_create_error, sizeof(g_create_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define RDC_HIP(ctx, call)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return fail(ctx, RDC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int dev_free(rdc_ctx* c, DevBuf& b) {
+  if (b.p && b.owned) {
+    hipError_t e = hipFree(b.p);
+    if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+  }
+  b = DevBuf();
+  return RDC_OK;
+}
+
+int dev_alloc(rdc_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.p && b.owned && b.bytes >= bytes && bytes > 0) return RDC_OK;
+  int rc = dev_free(c, b);
+  if (rc) return rc;
+  if (bytes == 0) bytes = 8;
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b = DevBuf();
+    return fail(c, RDC_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  b.bytes = bytes;
+  b.owned = true;
+  return RDC_OK;
+}
+
+template <class T>
+int dev_upload(rdc_ctx* c, DevBuf& b, const std::vector<T>& v) {
+  int rc = dev_alloc(c, b, v.size() * sizeof(T));
+  if (rc) return rc;
+  if (!v.empty()) RDC_HIP(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return RDC_OK;
+}
+
+int set_device(rdc_ctx* c) {
+  RDC_HIP(c, hipSetDevice(c->device));
+  return RDC_OK;
+}
+
+int64_t field_width(const rdc_ctx* c, int field) {
+  switch (field) {
+    case RDC_FIELD_OLD_SOLUTION: return c->prep.nvar;
+    case RDC_FIELD_AUX_NODAL: return 3;
+    case RDC_FIELD_UNDEFORMED_XYZ: return 3;
+    case RDC_FIELD_ELEM_FIBRE: return 3;
+  }
+  return 0;
+}
+
+int64_t field_expected(const rdc_ctx* c, int field) {
+  const int64_t rows = (field == RDC_FIELD_ELEM_FIBRE) ? c->prep.n_elem : c->prep.n_node;
+  return rows * field_width(c, field);
+}
+
+MeshDev mesh_view(const rdc_ctx* c) {
+  MeshDev m;
+  m.n_elem = c->prep.n_elem; m.n_node = c->prep.n_node; m.n_owned = c->prep.n_owned;
+  m.conn = (const uint32_t*)c->conn.p;
+  m.xyz = (const double*)c->xyz.p;
+  m.bptr = (const int64_t*)c->bptr.p;
+  m.eslot = (const uint16_t*)c->eslot.p;
+  m.elem_order = (const uint32_t*)c->elem_order.p;
+  m.first_mask = (const uint64_t*)c->first_mask.p;
+  m.first_rhs = (const uint8_t*)c->first_rhs.p;
+  m.pair_elem = (const uint32_t*)c->pair_elem.p;
+  m.pair_local = (const uint8_t*)c->pair_local.p;
+  m.node_pair_ptr = (const int64_t*)c->node_pair_ptr.p;
+  m.wg_node_ptr = (const int32_t*)c->wg_node_ptr.p;
+  return m;
+}
+
+int resolve_strategy(rdc_ctx* c, int* out) {
+  int s = c->strategy;
+  if (s == RDC_SCATTER_AUTO) s = c->prep.rowgather_ok ? RDC_SCATTER_ROWGATHER : RDC_SCATTER_COLOURED;
+  if (s == RDC_SCATTER_ROWGATHER && !c->prep.rowgather_ok)
+    return fail(c, RDC_ERR_UNSUPPORTED, "row-gather scatter unavailable: a node row exceeds the LDS budget");
+  *out = s;
+  return RDC_OK;
+}
+
+template <class M, class P>
+int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!p) return fail(c, RDC_ERR_INVALID, "null parameter struct");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "assemble called before rdc_mesh_upload");
+  if (c->prep.nvar != nvar_expected)
+    return fail(c, RDC_ERR_INVALID, "model needs nvar=%d, mesh was uploaded with nvar=%d", nvar_expected, c->prep.nvar);
+  if (!c->field[RDC_FIELD_OLD_SOLUTION].p) return fail(c, RDC_ERR_STATE, "old solution field not set");
+  if (need_aux && !c->field[RDC_FIELD_AUX_NODAL].p) return fail(c, RDC_ERR_STATE, "aux nodal field not set");
+  int rc = set_device(c);
+  if (rc) return rc;
+  const typename M::K k = M::derive(*p);
+  LaunchArgs a;
+  a.m = mesh_view(c);
+  a.nen = c->prep.nen;
+  a.exp_mode = exp_mode_of(M::exponent(k)) == 3 ? 3 : 0;
+  rc = resolve_strategy(c, &a.strategy);
+  if (rc) return rc;
+  a.u = (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p;
+  a.aux = (const double*)c->field[RDC_FIELD_AUX_NODAL].p;
+  a.packed = (double*)c->packed.p;
+  a.variant = c->variant;
+  a.val = (double*)c->val.p;
+  a.rhs = (double*)c->rhs.p;
+  a.stream = c->stream;
+  a.colour_ptr = c->prep.colour_ptr.data();
+  a.n_colours = c->prep.n_colours;
+  a.n_wg = c->prep.rowgather_ok ? (int)c->prep.wg_node_ptr.size() - 1 : 0;
+  a.lds_bytes = c->prep.rg_lds_bytes;
+  if (c->timing) RDC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  hipError_t e = launch_rd<M>(a, k);
+  if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  if (c->timing) {
+    RDC_HIP(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+  }
+  return RDC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdc_abi_version(void) { return RDC_ABI_VERSION; }
+
+const char* rdc_last_error(const rdc_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
+
+int rdc_ctx_create(int device_ordinal, rdc_ctx** out) {
+  if (!out) return fail(nullptr, RDC_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, RDC_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device_ordinal < 0 || device_ordinal >= ndev)
+    return fail(nullptr, RDC_ERR_INVALID, "device ordinal %d out of range [0,%d)", device_ordinal, ndev);
+  rdc_ctx* c = new (std::nothrow) rdc_ctx();
+  if (!c) return fail(nullptr, RDC_ERR_ALLOC, "out of host memory");
+  c->device = device_ordinal;
+  e = hipSetDevice(device_ordinal);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(nullptr, RDC_ERR_HIP, "device initialisation failed: %s", hipGetErrorString(e));
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.sharedMemPerBlock > 0)
+    c->max_lds = prop.sharedMemPerBlock;
+  *out = c;
+  return RDC_OK;
+}
+
+int rdc_ctx_destroy(rdc_ctx* c) {
+  if (!c) return RDC_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
+                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed,
+                   &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
+  for (DevBuf* b : all) dev_free(c, *b);
+  for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+  return RDC_OK;
+}
+
+int rdc_set_stream(rdc_ctx* c, void* s) {
+  if (!c) return RDC_ERR_INVALID;
+  c->stream = (hipStream_t)s;
+  return RDC_OK;
+}
+
+int rdc_synchronize(rdc_ctx* c) {
+  if (!c) return RDC_ERR_INVALID;
+  int rc = set_device(c);
+  if (rc) return rc;
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_set_scatter(rdc_ctx* c, int s) {
+  if (!c) return RDC_ERR_INVALID;
+  if (s != RDC_SCATTER_AUTO && s != RDC_SCATTER_COLOURED && s != RDC_SCATTER_ROWGATHER)
+    return fail(c, RDC_ERR_INVALID, "unknown scatter strategy %d", s);
+  c->strategy = s;
+  return RDC_OK;
+}
+
+int rdc_set_kernel_variant(rdc_ctx* c, int v) {
+  if (!c) return RDC_ERR_INVALID;
+  if (v != RDC_VARIANT_AUTO && v != RDC_VARIANT_GENERIC) return fail(c, RDC_ERR_INVALID, "unknown kernel variant %d", v);
+  c->variant = v;
+  return RDC_OK;
+}
+
+int rdc_get_scatter(const rdc_ctx* c, int* s) {
+  if (!c || !s) return RDC_ERR_INVALID;
+  int r = c->strategy;
+  if (r == RDC_SCATTER_AUTO && c->have_mesh) r = c->prep.rowgather_ok ? RDC_SCATTER_ROWGATHER : RDC_SCATTER_COLOURED;
+  *s = r;
+  return RDC_OK;
+}
+
+int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, int64_t n_owned,
+                    const uint32_t* conn, const double* xyz, int nvar) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!conn || !xyz) return fail(c, RDC_ERR_INVALID, "null mesh arrays");
+  int rc = set_device(c);
+  if (rc) return rc;
+  c->have_mesh = false;
+  // LDS budget of a row-gather workgroup: half the per-block limit keeps two workgroups per CU
+  const size_t budget = c->max_lds >= 64 * 1024 ? 60 * 1024 : c->max_lds / 2;
+  std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, 256, c->prep);
+  if (!err.empty()) return fail(c, RDC_ERR_INVALID, "%s", err.c_str());
+  const HostPrep& P = c->prep;
+  std::vector<uint32_t> conn_v(conn, conn + n_elem * elem_type);
+  std::vector<double> xyz_v(xyz, xyz + n_node * 3);
+  if ((rc = dev_upload(c, c->conn, conn_v))) return rc;
+  if ((rc = dev_upload(c, c->xyz, xyz_v))) return rc;
+  if ((rc = dev_upload(c, c->bptr, P.bptr))) return rc;
+  if ((rc = dev_upload(c, c->eslot, P.eslot))) return rc;
+  if ((rc = dev_upload(c, c->elem_order, P.elem_order))) return rc;
+  if ((rc = dev_upload(c, c->first_mask, P.first_mask))) return rc;
+  if ((rc = dev_upload(c, c->first_rhs, P.first_rhs))) return rc;
+  if ((rc = dev_upload(c, c->pair_elem, P.pair_elem))) return rc;
+  if ((rc = dev_upload(c, c->pair_local, P.pair_local))) return rc;
+  if ((rc = dev_upload(c, c->node_pair_ptr, P.node_pair_ptr))) return rc;
+  if ((rc = dev_upload(c, c->wg_node_ptr, P.wg_node_ptr))) return rc;
+  const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
+  if ((rc = dev_alloc(c, c->val, nnz * sizeof(double)))) return rc;
+  if ((rc = dev_alloc(c, c->rhs, (size_t)n_owned * nvar * sizeof(double)))) return rc;
+  if (elem_type == RDC_TET4 && (rc = dev_alloc(c, c->packed, (size_t)n_node * 12 * sizeof(double)))) return rc;
+  RDC_HIP(c, hipMemsetAsync(c->val.p, 0, c->val.bytes, c->stream));
+  RDC_HIP(c, hipMemsetAsync(c->rhs.p, 0, c->rhs.bytes, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  // fields are tied to the mesh sizes: drop library-owned ones
+  for (int f = 0; f < RDC_FIELD_COUNT; f++) { dev_free(c, c->field[f]); c->field_count[f] = 0; }
+  dev_free(c, c->elem_material); dev_free(c, c->materials);
+  dev_free(c, c->side_elem); dev_free(c, c->side_id); dev_free(c, c->side_disp);
+  c->n_materials = 0; c->n_sides = 0;
+  c->have_mesh = true;
+  return RDC_OK;
+}
+
+int rdc_mesh_update_coords(rdc_ctx* c, const double* xyz) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (!xyz) return fail(c, RDC_ERR_INVALID, "null coordinates");
+  int rc = set_device(c);
+  if (rc) return rc;
+  RDC_HIP(c, hipMemcpyAsync(c->xyz.p, xyz, (size_t)c->prep.n_node * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_mesh_coords_device_ptr(rdc_ctx* c, double** d) {
+  if (!c || !d) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  *d = (double*)c->xyz.p;
+  return RDC_OK;
+}
+
+int rdc_mesh_dims(const rdc_ctx* c, int64_t* n_elem, int64_t* n_node, int64_t* n_owned, int* elem_type,
+                  int* nvar, int* n_colours) {
+  if (!c || !c->have_mesh) return RDC_ERR_STATE;
+  if (n_elem) *n_elem = c->prep.n_elem;
+  if (n_node) *n_node = c->prep.n_node;
+  if (n_owned) *n_owned = c->prep.n_owned;
+  if (elem_type) *elem_type = c->prep.nen;
+  if (nvar) *nvar = c->prep.nvar;
+  if (n_colours) *n_colours = c->prep.n_colours;
+  return RDC_OK;
+}
+
+int rdc_csr_dims(const rdc_ctx* c, int64_t* n_rows, int64_t* nnz) {
+  if (!c || !c->have_mesh) return RDC_ERR_STATE;
+  if (n_rows) *n_rows = c->prep.n_owned * c->prep.nvar;
+  if (nnz) *nnz = (int64_t)c->prep.nvar * c->prep.nvar * c->prep.bptr[c->prep.n_owned];
+  return RDC_OK;
+}
+
+int rdc_csr_pattern_download(const rdc_ctx* c, int64_t* row_ptr, int32_t* col_idx) {
+  if (!c || !c->have_mesh) return RDC_ERR_STATE;
+  if (!row_ptr || !col_idx) return RDC_ERR_INVALID;
+  const HostPrep& P = c->prep;
+  const int nv = P.nvar;
+  row_ptr[0] = 0;
+  for (int64_t n = 0; n < P.n_owned; n++) {
+    const int64_t len = P.bptr[n + 1] - P.bptr[n];
+    for (int a = 0; a < nv; a++) {
+      const int64_t r = n * nv + a;
+      row_ptr[r + 1] = row_ptr[r] + len * nv;
+      int32_t* o = col_idx + row_ptr[r];
+      for (int64_t k = 0; k < len; k++)
+        for (int b = 0; b < nv; b++) *o++ = P.bcol[P.bptr[n] + k] * nv + b;
+    }
+  }
+  return RDC_OK;
+}
+
+int rdc_mesh_colours_download(const rdc_ctx* c, int32_t* colour) {
+  if (!c || !c->have_mesh) return RDC_ERR_STATE;
+  if (!colour) return RDC_ERR_INVALID;
+  std::memcpy(colour, c->prep.colour.data(), sizeof(int32_t) * (size_t)c->prep.n_elem);
+  return RDC_OK;
+}
+
+int rdc_field_device_ptr(rdc_ctx* c, int field, int64_t count, double** d_ptr) {
+  if (!c || !d_ptr) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (field < 0 || field >= RDC_FIELD_COUNT) return fail(c, RDC_ERR_INVALID, "unknown field %d", field);
+  if (count != field_expected(c, field))
+    return fail(c, RDC_ERR_INVALID, "field %d needs %lld values, got %lld", field, (long long)field_expected(c, field), (long long)count);
+  int rc = set_device(c);
+  if (rc) return rc;
+  DevBuf& b = c->field[field];
+  if (!b.p || !b.owned || c->field_count[field] != count) {
+    if (b.p && !b.owned) b = DevBuf();
+    if ((rc = dev_alloc(c, b, (size_t)count * sizeof(double)))) return rc;
+    c->field_count[field] = count;
+  }
+  *d_ptr = (double*)b.p;
+  return RDC_OK;
+}
+
+int rdc_field_upload(rdc_ctx* c, int field, const double* host, int64_t count) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!host) return fail(c, RDC_ERR_INVALID, "null host pointer");
+  double* d = nullptr;
+  int rc = rdc_field_device_ptr(c, field, count, &d);
+  if (rc) return rc;
+  RDC_HIP(c, hipMemcpyAsync(d, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_field_download(rdc_ctx* c, int field, double* host, int64_t count) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!host) return fail(c, RDC_ERR_INVALID, "null host pointer");
+  if (field < 0 || field >= RDC_FIELD_COUNT || !c->field[field].p) return fail(c, RDC_ERR_STATE, "field %d not set", field);
+  if (count != c->field_count[field]) return fail(c, RDC_ERR_INVALID, "field %d holds %lld values", field, (long long)c->field_count[field]);
+  int rc = set_device(c);
+  if (rc) return rc;
+  RDC_HIP(c, hipMemcpyAsync(host, c->field[field].p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_field_bind_device(rdc_ctx* c, int field, double* d_ptr, int64_t count) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (field < 0 || field >= RDC_FIELD_COUNT) return fail(c, RDC_ERR_INVALID, "unknown field %d", field);
+  if (!d_ptr) return fail(c, RDC_ERR_INVALID, "null device pointer");
+  if (count != field_expected(c, field))
+    return fail(c, RDC_ERR_INVALID, "field %d needs %lld values, got %lld", field, (long long)field_expected(c, field), (long long)count);
+  int rc = dev_free(c, c->field[field]);
+  if (rc) return rc;
+  c->field[field].p = d_ptr;
+  c->field[field].bytes = (size_t)count * sizeof(double);
+  c->field[field].owned = false;
+  c->field_count[field] = count;
+  return RDC_OK;
+}
+
+int rdc_solid_set_materials(rdc_ctx* c, const int32_t* elem_material, int32_t n_materials,
+                            const rdc_solid_material* materials) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (!elem_material || !materials || n_materials <= 0) return fail(c, RDC_ERR_INVALID, "bad material table");
+  for (int64_t e = 0; e < c->prep.n_elem; e++)
+    if (elem_material[e] < 0 || elem_material[e] >= n_materials) return fail(c, RDC_ERR_INVALID, "material index out of range at element %lld", (long long)e);
+  int rc = set_device(c);
+  if (rc) return rc;
+  std::vector<int32_t> em(elem_material, elem_material + c->prep.n_elem);
+  std::vector<rdc_solid_material> mt(materials, materials + n_materials);
+  if ((rc = dev_upload(c, c->elem_material, em))) return rc;
+  if ((rc = dev_upload(c, c->materials, mt))) return rc;
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  c->n_materials = n_materials;
+  return RDC_OK;
+}
+
+int rdc_solid_set_sides(rdc_ctx* c, int64_t n_sides, const int64_t* side_elem, const int32_t* side_id,
+                        const double* side_disp) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (n_sides < 0 || (n_sides > 0 && (!side_elem || !side_id || !side_disp))) return fail(c, RDC_ERR_INVALID, "bad side list");
+  const int nsides_elem = c->prep.nen == 4 ? 4 : 6;
+  for (int64_t s = 0; s < n_sides; s++) {
+    if (side_elem[s] < 0 || side_elem[s] >= c->prep.n_elem) return fail(c, RDC_ERR_INVALID, "side %lld: element out of range", (long long)s);
+    if (side_id[s] < 0 || side_id[s] >= nsides_elem) return fail(c, RDC_ERR_INVALID, "side %lld: side id out of range", (long long)s);
+  }
+  int rc = set_device(c);
+  if (rc) return rc;
+  std::vector<int64_t> se(side_elem, side_elem + n_sides);
+  std::vector<int32_t> si(side_id, side_id + n_sides);
+  std::vector<double> sd(side_disp, side_disp + 3 * n_sides);
+  if ((rc = dev_upload(c, c->side_elem, se))) return rc;
+  if ((rc = dev_upload(c, c->side_id, si))) return rc;
+  if ((rc = dev_upload(c, c->side_disp, sd))) return rc;
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  c->n_sides = n_sides;
+  return RDC_OK;
+}
+
+int rdc_assemble_pihna(rdc_ctx* c, const rdc_pihna_params* p) { return assemble_rd<Pihna>(c, p, 5, false); }
+int rdc_assemble_ripf(rdc_ctx* c, const rdc_ripf_params* p) { return assemble_rd<Ripf>(c, p, 3, true); }
+int rdc_assemble_hcc(rdc_ctx* c, const rdc_hcc_params* p) { return assemble_rd<Hcc>(c, p, 3, false); }
+
+int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobian) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!p) return fail(c, RDC_ERR_INVALID, "null parameter struct");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "assemble called before rdc_mesh_upload");
+  if (c->prep.nvar != 3) return fail(c, RDC_ERR_INVALID, "solid system needs nvar=3");
+  if (!c->field[RDC_FIELD_UNDEFORMED_XYZ].p) return fail(c, RDC_ERR_STATE, "undeformed coordinates not set");
+  if (!c->field[RDC_FIELD_ELEM_FIBRE].p) return fail(c, RDC_ERR_STATE, "fibre field not set");
+  if (c->n_materials <= 0) return fail(c, RDC_ERR_STATE, "materials not set");
+  int rc = set_device(c);
+  if (rc) return rc;
+  SolidArgs a;
+  a.m = mesh_view(c);
+  a.nen = c->prep.nen;
+  a.Xu = (const double*)c->field[RDC_FIELD_UNDEFORMED_XYZ].p;
+  a.fibre = (const double*)c->field[RDC_FIELD_ELEM_FIBRE].p;
+  a.elem_material = (const int32_t*)c->elem_material.p;
+  a.materials = (const rdc_solid_material*)c->materials.p;
+  a.n_sides = c->n_sides;
+  a.side_elem = (const int64_t*)c->side_elem.p;
+  a.side_id = (const int32_t*)c->side_id.p;
+  a.side_disp = (const double*)c->side_disp.p;
+  a.params = *p;
+  a.request_jacobian = request_jacobian;
+  a.val = (double*)c->val.p;
+  a.rhs = (double*)c->rhs.p;
+  a.stream = c->stream;
+  a.colour_ptr = c->prep.colour_ptr.data();
+  a.n_colours = c->prep.n_colours;
+  if (c->timing) RDC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  hipError_t e = launch_solid(a);
+  if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "solid kernel launch failed: %s", hipGetErrorString(e));
+  if (c->timing) {
+    RDC_HIP(c, hipEventRecord(c->ev1, c->stream));
+    c->ev_valid = true;
+  }
+  return RDC_OK;
+}
+
+int rdc_csr_values_device_ptr(rdc_ctx* c, double** d_val, double** d_rhs) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (d_val) *d_val = (double*)c->val.p;
+  if (d_rhs) *d_rhs = (double*)c->rhs.p;
+  return RDC_OK;
+}
+
+int rdc_csr_download(rdc_ctx* c, double* val, double* rhs) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  int rc = set_device(c);
+  if (rc) return rc;
+  const size_t nnz = (size_t)c->prep.nvar * c->prep.nvar * c->prep.bptr[c->prep.n_owned];
+  if (val) RDC_HIP(c, hipMemcpyAsync(val, c->val.p, nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (rhs) RDC_HIP(c, hipMemcpyAsync(rhs, c->rhs.p, (size_t)c->prep.n_owned * c->prep.nvar * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_clamp_nonnegative(rdc_ctx* c, int field) {
+  if (!c) return RDC_ERR_INVALID;
+  if (field < 0 || field >= RDC_FIELD_COUNT || !c->field[field].p) return fail(c, RDC_ERR_STATE, "field %d not set", field);
+  int rc = set_device(c);
+  if (rc) return rc;
+  const int64_t n = c->field_count[field];
+  if (n > 0) {
+    int64_t grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_clamp_nonnegative, dim3((unsigned)grid), dim3(256), 0, c->stream, (double*)c->field[field].p, n);
+    RDC_HIP(c, hipGetLastError());
+  }
+  return RDC_OK;
+}
+
+int rdc_timing_enable(rdc_ctx* c, int on) {
+  if (!c) return RDC_ERR_INVALID;
+  c->timing = on != 0;
+  c->ev_valid = false;
+  return RDC_OK;
+}
+
+int rdc_timing_last_ms(rdc_ctx* c, float* ms) {
+  if (!c || !ms) return RDC_ERR_INVALID;
+  if (!c->ev_valid) return fail(c, RDC_ERR_STATE, "no timed assemble call recorded");
+  int rc = set_device(c);
+  if (rc) return rc;
+  RDC_HIP(c, hipEventSynchronize(c->ev1));
+  RDC_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return RDC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// rdc_integrands.h — weak-form integrands of the reaction-diffusion-convection models in
+// "coefficient form".
+//
+// Every Ke/Fe contribution of the reference callbacks has the shape
+//
+//   Ke_ab(i,j) += JxW * [ A_ab * phi_j*phi_i  +  phi_j * sum_k B_ab^k * (grad f_k . grad phi_i)
+//                         +  D_ab * (grad phi_j . grad phi_i) ]
+//   Fe_a(i)    += JxW * [ R_a * phi_i  +  sum_k RG_a^k * (grad f_k . grad phi_i) ]
+//
+// where A, B, D, R, RG depend only on the old solution at the quadrature point.  This file
+// evaluates those point coefficients; the kernels (rdc_kernels.h) contract them with the shape
+// data.  On TET4 (constant gradients) the contraction collapses into a handful of quadrature
+// moments, which is what the fast path exploits.
+//
+// Reference lines restated here:
+//   PIHNA  src/pihna.C:358-381 (constants), :444-509 (point nonlinearities), :514-747 (terms)
+//   RIPF   src/ripf.C:377-408, :486-561, :566-662
+//   HCC    src/coupled_hcc.C:450-461, :510-535, :540-637   (quirks of App. D reproduced)
+#ifndef RDC_INTEGRANDS_H
+#define RDC_INTEGRANDS_H
+
+#include <math.h>
+#include "../../include/rdc_assembly.h"
+
+#if defined(__HIPCC__)
+#define RDC_HD __host__ __device__ __forceinline__
+#else
+#define RDC_HD inline
+#endif
+
+namespace rdc {
+
+// ---- generic coefficient container -------------------------------------------------------
+template <int NV, int NG>
+struct Coef {
+  double A[NV][NV];      // mass-type
+  double B[NV][NV][NG];  // phi_j * (grad f_k . grad phi_i)
+  double D[NV][NV];      // stiffness-type
+  double R[NV];          // rhs mass-type
+  double RG[NV][NG];     // rhs gradient-type
+  RDC_HD void zero() {
+    for (int a = 0; a < NV; a++) {
+      R[a] = 0.0;
+      for (int k = 0; k < NG; k++) RG[a][k] = 0.0;
+      for (int b = 0; b < NV; b++) {
+        A[a][b] = 0.0;
+        D[a][b] = 0.0;
+        for (int k = 0; k < NG; k++) B[a][b][k] = 0.0;
+      }
+    }
+  }
+};
+
+// x^e for the crowding functions.  The reference calls pow(1-Te, ek) with a real exponent
+// (src/pihna.C:466); for the small integer exponents of the shipped inputs (ek = 3) the host
+// selects EXP_MODE = that integer and the power is formed by multiplication (<= 1 ulp from pow).
+// EXP_MODE 0 = general real exponent.  p = x^e, pm1 = x^(e-1).
+template <int EXP_MODE>
+RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
+  if (EXP_MODE == 1) { pm1 = 1.0; p = x; }
+  else if (EXP_MODE == 2) { pm1 = x; p = x * x; }
+  else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
+  else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
+  else { p = pow(x, e); pm1 = pow(x, e - 1.0); }
+}
+
+// =========================================================================================
+// PIHNA: unknowns (n, c, h, v, a); gradient fields k = 0..3 -> (c, h, v, a)
+// =========================================================================================
+struct PihnaK {  // src/pihna.C:358-381
+  double DT2, Lambda, Kappa, Ka, ek;
+  double nec_c, nec_h, nec_v;
+  double dif_c, tax_c, dif_h, tax_h, prod_c, c2h, h2c, h2n;
+  double dif_v, tax_v, prod_v;
+  double sec_c, sec_h, upt, dec;
+};
+
+struct Pihna {
+  static constexpr int NV = 5, NG = 4, NAUX = 0;
+  using K = PihnaK;
+  using C = Coef<NV, NG>;
+  // which nodal array feeds gradient field k: index into u (>=0)
+  RDC_HD static constexpr int grad_src(int k) { return k + 1; }
+  // structural sparsity of coef(): entries outside these masks are identically zero
+  RDC_HD static constexpr bool hasA(int a, int b) {
+    return !((a == 0 && b == 4) || (a == 4 && b == 0) || (a == 1 && b == 4) || (a == 2 && b == 4));
+  }
+  RDC_HD static constexpr bool hasB(int a, int b, int k) {
+    return b < 4 && ((a == 1 && (k == 0 || k == 2)) || (a == 2 && (k == 1 || k == 2)) || (a == 3 && (k == 2 || k == 3)));
+  }
+  RDC_HD static constexpr bool hasD(int a, int b) {
+    return (a == 1 && (b == 1 || b == 3)) || (a == 2 && (b == 2 || b == 3)) || (a == 3 && (b == 3 || b == 4));
+  }
+  RDC_HD static constexpr bool hasRG(int a, int k) {
+    return (a == 1 && (k == 0 || k == 2)) || (a == 2 && (k == 1 || k == 2)) || (a == 3 && (k == 2 || k == 3));
+  }
+
+  static inline K derive(const rdc_pihna_params& p) {
+    K k;
+    k.DT2 = p.time_step / 2.0;
+    k.Lambda = p.cells_min_capacity;
+    k.Kappa = p.cells_max_capacity;
+    k.Ka = p.cytokines_max_capacity;
+    k.ek = p.cells_max_capacity_exponent;
+    k.nec_c = p.necrosis_c / k.Kappa;  // :364-366
+    k.nec_h = p.necrosis_h / k.Kappa;
+    k.nec_v = p.necrosis_v / k.Kappa;
+    k.dif_c = p.diffuse_c; k.tax_c = p.taxis_c; k.dif_h = p.diffuse_h; k.tax_h = p.taxis_h;
+    k.prod_c = p.produce_c; k.c2h = p.switch_c2h; k.h2c = p.switch_h2c; k.h2n = p.switch_h2n;
+    k.dif_v = p.diffuse_v; k.tax_v = p.taxis_v; k.prod_v = p.produce_v;
+    k.sec_c = p.secrete_a_c; k.sec_h = p.secrete_a_h; k.upt = p.uptake_a_v; k.dec = p.decay_a;
+    return k;
+  }
+  static inline double exponent(const K& k) { return k.ek; }
+
+  // point nonlinearities shared by all terms
+  struct Pt {
+    double n, c, h, v, a;
+    double Tau, dT;            // crowding and its (common) derivative          :444-472
+    double Ve, Ve_dc, Ve_dv;   // vascular fraction; d/dh == d/dc               :474-499
+    double Ua, Ua_da;          // cytokine uptake                               :501-502
+    double dif_c, tax_c, dif_h, tax_h, dif_v, tax_v;  // thresholded transport  :504-509
+  };
+
+  template <int EXP_MODE>
+  RDC_HD static void point(const K& k, const double* u, const double* /*aux*/, Pt& s) {
+    s.n = u[0]; s.c = u[1]; s.h = u[2]; s.v = u[3]; s.a = u[4];
+    const double Te = (s.n + s.c + s.h + s.v) / k.Kappa;
+    if (Te <= 0.0) { s.Tau = 1.0; s.dT = 0.0; }
+    else if (Te >= 1.0) { s.Tau = 0.0; s.dT = 0.0; }
+    else {
+      double p, pm1;
+      pow_pair<EXP_MODE>(1.0 - Te, k.ek, p, pm1);
+      s.Tau = p;
+      s.dT = (-k.ek / k.Kappa) * pm1;
+    }
+    const double chv = s.c + s.h + s.v;
+    const double Ve_ = s.v / chv;  // NaN for chv == 0 drops into the last branch, as upstream
+    if (Ve_ <= 0.0) { s.Ve = 0.0; s.Ve_dc = 0.0; s.Ve_dv = 0.0; }
+    else if (Ve_ >= 1.0) { s.Ve = 1.0; s.Ve_dc = 0.0; s.Ve_dv = 0.0; }
+    else { s.Ve = Ve_; s.Ve_dc = -Ve_ / chv; s.Ve_dv = (1.0 - Ve_) / chv; }
+    const double aK = s.a + k.Ka;
+    s.Ua = s.a / aK;
+    s.Ua_da = 1.0 / aK - s.Ua / aK;
+    s.dif_c = (s.c > k.Lambda ? k.dif_c : 0.0); s.tax_c = (s.c > k.Lambda ? k.tax_c : 0.0);
+    s.dif_h = (s.h > k.Lambda ? k.dif_h : 0.0); s.tax_h = (s.h > k.Lambda ? k.tax_h : 0.0);
+    s.dif_v = (s.v > k.Lambda ? k.dif_v : 0.0); s.tax_v = (s.v > k.Lambda ? k.tax_v : 0.0);
+  }
+
+  // coefficients of equation row `a` only would be enough for a row kernel, but the full set is
+  // cheap relative to the contraction; the compiler drops what a caller does not consume.
+  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    const double oneVe = 1.0 - s.Ve;
+    const double nVe_dc = -s.Ve_dc, nVe_dv = -s.Ve_dv;  // (-Ve__dc) etc. as written upstream
+    // ---- n equation, :514-522 and :571-597
+    o.R[0] = s.n + T * (k.nec_c * s.c * s.n + k.nec_h * s.h * s.n + k.nec_v * s.v * s.n + k.h2n * oneVe * s.h);
+    o.A[0][0] = 1.0 - T * (k.nec_c * s.c + k.nec_h * s.h + k.nec_v * s.v);
+    o.A[0][1] = -T * (k.nec_c * s.n + k.h2n * nVe_dc * s.h);
+    o.A[0][2] = -T * (k.nec_h * s.n + k.h2n * nVe_dc * s.h + k.h2n * oneVe);
+    o.A[0][3] = -T * (k.nec_v * s.n + k.h2n * nVe_dv * s.h);
+    // ---- c equation, :524-534 and :599-641   (gradient fields: 0 = c, 2 = v)
+    const double pc = k.prod_c * s.dT * s.c;
+    o.R[1] = s.c + T * (k.prod_c * s.Tau * s.c - k.c2h * oneVe * s.c + k.h2c * s.Ve * s.h - k.nec_c * s.c * s.n);
+    o.RG[1][0] = -T * s.dif_c * s.Tau;
+    o.RG[1][2] = -T * s.tax_c * s.Tau * s.c;
+    o.A[1][0] = -T * (pc - k.nec_c * s.c);
+    o.A[1][1] = 1.0 - T * (k.prod_c * s.Tau + pc - k.c2h * oneVe - k.c2h * nVe_dc * s.c + k.h2c * s.Ve_dc * s.h - k.nec_c * s.n);
+    o.A[1][2] = -T * (pc - k.c2h * nVe_dc * s.c + k.h2c * s.Ve_dc * s.h + k.h2c * s.Ve);
+    o.A[1][3] = -T * (pc - k.c2h * nVe_dv * s.c + k.h2c * s.Ve_dv * s.h);
+    {
+      const double bc = T * s.dif_c * s.dT, bv = T * s.tax_c * s.dT * s.c;
+      for (int b = 0; b < 4; b++) { o.B[1][b][0] = bc; o.B[1][b][2] = bv; }
+      o.B[1][1][2] += T * s.tax_c * s.Tau;
+    }
+    o.D[1][1] = T * s.dif_c * s.Tau;
+    o.D[1][3] = T * s.tax_c * s.Tau * s.c;
+    // ---- h equation, :536-546 and :643-684   (gradient fields: 1 = h, 2 = v)
+    o.R[2] = s.h + T * (k.c2h * oneVe * s.c - k.h2c * s.Ve * s.h - k.nec_h * s.h * s.n - k.h2n * oneVe * s.h);
+    o.RG[2][1] = -T * s.dif_h * s.Tau;
+    o.RG[2][2] = -T * s.tax_h * s.Tau * s.h;
+    o.A[2][0] = T * k.nec_h * s.h;
+    o.A[2][1] = -T * (k.c2h * oneVe + k.c2h * nVe_dc * s.c - k.h2c * s.Ve_dc * s.h - k.h2n * nVe_dc * s.h);
+    o.A[2][2] = 1.0 - T * (k.c2h * nVe_dc * s.c - k.h2c * s.Ve_dc * s.h - k.h2c * s.Ve - k.nec_h * s.n -
+                           k.h2n * nVe_dc * s.h - k.h2n * oneVe);
+    o.A[2][3] = -T * (k.c2h * nVe_dv * s.c - k.h2c * s.Ve_dv * s.h - k.h2n * nVe_dv * s.h);
+    {
+      const double bh = T * s.dif_h * s.dT, bv = T * s.tax_h * s.dT * s.h;
+      for (int b = 0; b < 4; b++) { o.B[2][b][1] = bh; o.B[2][b][2] = bv; }
+      o.B[2][2][2] += T * s.tax_h * s.Tau;
+    }
+    o.D[2][2] = T * s.dif_h * s.Tau;
+    o.D[2][3] = T * s.tax_h * s.Tau * s.h;
+    // ---- v equation, :548-556 and :686-724   (gradient fields: 2 = v, 3 = a)
+    const double pv = k.prod_v * s.dT * s.Ua * s.v;
+    o.R[3] = s.v + T * (k.prod_v * s.Tau * s.Ua * s.v - k.nec_v * s.v * s.n);
+    o.RG[3][2] = -T * s.dif_v * s.Tau;
+    o.RG[3][3] = -T * s.tax_v * s.Tau * s.v;
+    o.A[3][0] = -T * (pv - k.nec_v * s.v);
+    o.A[3][1] = -T * pv;
+    o.A[3][2] = -T * pv;
+    o.A[3][3] = 1.0 - T * (pv - k.nec_v * s.n);
+    o.A[3][4] = -T * (k.prod_v * s.Tau * s.Ua_da * s.v);
+    {
+      const double bv = T * s.dif_v * s.dT, ba = T * s.tax_v * s.dT * s.v;
+      for (int b = 0; b < 4; b++) { o.B[3][b][2] = bv; o.B[3][b][3] = ba; }
+      o.B[3][3][3] += T * s.tax_v * s.Tau;
+    }
+    o.D[3][3] = T * s.dif_v * s.Tau;
+    o.D[3][4] = T * s.tax_v * s.Tau * s.v;
+    // ---- a equation, :558-566 and :726-747
+    o.R[4] = s.a + T * (k.sec_c * s.c + k.sec_h * s.h - k.upt * s.v * s.a - k.dec * s.a);
+    o.A[4][1] = -T * k.sec_c;
+    o.A[4][2] = -T * k.sec_h;
+    o.A[4][3] = T * k.upt * s.a;
+    o.A[4][4] = 1.0 + T * (k.upt * s.v + k.dec);
+  }
+};
+
+// =========================================================================================
+// RIPF: unknowns (HU, cc, fb); aux nodal (cc_dtime, fb_dtime, RT_total);
+// gradient fields k: 0 = fb, 1 = HU, 2 = RT_total (normalised to unit length, :481-484)
+// =========================================================================================
+struct RipfK {
+  double DT2;
+  double VF_fixed, VF_exp, VF_min;
+  double phi_cc_B, phi_cc_D, phi_cc, phi_fb_B, phi_fb_D, phi_fb, phi_tol;
+  double kappa, kappa_RT_c, delta, delta_RT_a, delta_RT_b;
+  double lambda, lambda_RT_r, lambda_HU_r, omicro, omicro_RT_r, omicro_fb_b;
+  double omega, diffusion, haptotaxis, radiotaxis;
+};
+
+struct Ripf {
+  static constexpr int NV = 3, NG = 3, NAUX = 3;
+  using K = RipfK;
+  using C = Coef<NV, NG>;
+  // gradient field sources: >=0 index into u, <0 -> aux index (-1-k)
+  RDC_HD static constexpr int grad_src(int k) { return k == 0 ? 2 : (k == 1 ? 0 : -3); }
+  RDC_HD static constexpr bool hasA(int a, int b) { return !((a == 1 && b == 0)); }
+  RDC_HD static constexpr bool hasB(int a, int b, int) { return a == 2 && b >= 1; }
+  RDC_HD static constexpr bool hasD(int a, int b) { return a == 2 && (b == 0 || b == 2); }
+  RDC_HD static constexpr bool hasRG(int a, int) { return a == 2; }
+
+  static inline K derive(const rdc_ripf_params& p) {
+    K k;
+    k.DT2 = p.time_step / 2.0;
+    k.VF_fixed = p.VolFr_stroma + p.VolFr_parenchyma;  // summed left-to-right as in :499
+    k.VF_exp = p.VolFr_exponent;
+    k.VF_min = p.VolFr_min_vacant;
+    k.phi_cc_B = p.phi_cc_B; k.phi_cc_D = p.phi_cc_D; k.phi_cc = p.phi_cc;
+    k.phi_fb_B = p.phi_fb_B; k.phi_fb_D = p.phi_fb_D; k.phi_fb = p.phi_fb; k.phi_tol = p.phi_tol;
+    k.kappa = p.kappa; k.kappa_RT_c = p.kappa_RT_c;
+    k.delta = p.delta; k.delta_RT_a = p.delta_RT_a; k.delta_RT_b = p.delta_RT_b;
+    k.lambda = p.lambda;
+    k.lambda_RT_r = p.lambda_RT_r ? p.lambda_RT_r : (double)p.RT_dose_total_max;  // :398-403
+    k.lambda_HU_r = p.lambda_HU_r;
+    k.omicro = p.omicro;
+    k.omicro_RT_r = p.omicro_RT_r ? p.omicro_RT_r : (double)p.RT_dose_total_max;
+    k.omicro_fb_b = p.omicro_fb_b;
+    k.omega = p.omega; k.diffusion = p.diffusion; k.haptotaxis = p.haptotaxis; k.radiotaxis = p.radiotaxis;
+    return k;
+  }
+  static inline double exponent(const K& k) { return k.VF_exp; }
+
+  struct Pt {
+    double HU, cc, fb, cc_dt, fb_dt;
+    double kappa_RT, delta_RT, lambda_RT, omicro_RT, eps_cc, eps_fb;
+    double Tau, dTau, Koppa, Koppa_dcc;
+    double Lom, Lom_dHU, Lom_dfb, Ome, Ome_dfb;
+  };
+
+  template <int EXP_MODE>
+  RDC_HD static void point(const K& k, const double* u, const double* aux, Pt& s) {
+    s.HU = u[0]; s.cc = u[1]; s.fb = u[2];
+    s.cc_dt = aux[0]; s.fb_dt = aux[1];
+    const double RT = aux[2];
+    s.kappa_RT = k.kappa * exp(-k.kappa_RT_c * RT);                                   // :486
+    s.delta_RT = k.delta * (1.0 - exp(-k.delta_RT_a * RT - k.delta_RT_b * (RT * RT)));  // :487
+    s.lambda_RT = k.lambda * (RT / k.lambda_RT_r);                                     // :488
+    {
+      const double r = RT / k.omicro_RT_r;                                            // :489
+      const double x = 4.0 * (r - r * r);
+      s.omicro_RT = k.omicro * (x < 0.0 ? 0.0 : x);
+    }
+    s.eps_cc = 0.0; s.eps_fb = 0.0;                                                   // :491-496
+    if (s.cc_dt > k.phi_tol) s.eps_cc = k.phi_cc_B; else if (s.cc_dt < -k.phi_tol) s.eps_cc = k.phi_cc_D;
+    if (s.fb_dt > k.phi_tol) s.eps_fb = k.phi_fb_B; else if (s.fb_dt < -k.phi_tol) s.eps_fb = k.phi_fb_D;
+    const double VF = k.VF_fixed + (s.cc + s.fb);                                     // :498-499
+    s.Tau = 0.0; s.dTau = 0.0;
+    if (VF < 1.0) {                                                                   // :503-514
+      double p, pm1;
+      pow_pair<EXP_MODE>(1.0 - VF, k.VF_exp, p, pm1);
+      s.Tau = p;
+      s.dTau = -k.VF_exp * pm1;
+      if (s.Tau < k.VF_min) { s.Tau = 0.0; s.dTau = 0.0; }
+    }
+    s.Koppa = 0.0; s.Koppa_dcc = 0.0;                                                 // :516-523
+    if (s.cc >= 0.0 && s.cc < 1.0) { s.Koppa = 4.0 * (s.cc - s.cc * s.cc); s.Koppa_dcc = 4.0 - 8.0 * s.cc; }
+    s.Lom = s.Lom_dHU = s.Lom_dfb = 0.0; s.Ome = s.Ome_dfb = 0.0;                     // :525-561
+    if (s.fb >= 0.0 && s.fb < 1.0) {
+      const double f2 = 1.0 - s.fb * s.fb;
+      if (s.HU > k.lambda_HU_r && s.HU < 0.0) {
+        s.Lom = f2 * (s.HU / k.lambda_HU_r);
+        s.Lom_dHU = f2 / k.lambda_HU_r;
+        s.Lom_dfb = -(2.0 * s.fb) * (s.HU / k.lambda_HU_r);
+      } else if (s.HU < k.lambda_HU_r) {
+        s.Lom = f2;
+        s.Lom_dfb = -(2.0 * s.fb);
+      }
+      if (s.fb <= k.omicro_fb_b) {
+        s.Ome = 4.0 * (k.omicro_fb_b - k.omicro_fb_b * k.omicro_fb_b);
+      } else {
+        s.Ome = 4.0 * (s.fb - s.fb * s.fb);
+        s.Ome_dfb = 4.0 - 8.0 * s.fb;
+      }
+    }
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    // HU equation, :566-574, :599-613
+    o.R[0] = s.HU + T * (s.eps_cc * s.cc + s.eps_fb * s.fb + k.phi_cc * s.cc_dt + k.phi_fb * s.fb_dt);
+    o.A[0][0] = 1.0;
+    o.A[0][1] = -T * s.eps_cc;
+    o.A[0][2] = -T * s.eps_fb;
+    // cc equation, :576-582, :615-627
+    o.R[1] = s.cc + T * (s.kappa_RT * s.Tau * s.Koppa - s.delta_RT * s.cc);
+    o.A[1][1] = 1.0 - T * (s.kappa_RT * s.dTau * s.Koppa + s.kappa_RT * s.Tau * s.Koppa_dcc - s.delta_RT);
+    o.A[1][2] = -T * (s.kappa_RT * s.dTau * s.Koppa);
+    // fb equation, :584-594, :629-662  (Lombda__dcc, Omecro__dHU, Omecro__dcc are identically 0)
+    const double src = s.lambda_RT * s.dTau * s.Lom + s.omicro_RT * s.dTau * s.Ome;
+    o.R[2] = s.fb + T * (s.lambda_RT * s.Tau * s.Lom + s.omicro_RT * s.Tau * s.Ome - k.omega * s.fb);
+    o.RG[2][0] = -T * k.diffusion * s.Tau;
+    o.RG[2][1] = -T * k.haptotaxis * s.Tau * s.fb;
+    o.RG[2][2] = -T * k.radiotaxis * s.Tau * s.fb;
+    o.A[2][0] = -T * (s.lambda_RT * s.Tau * s.Lom_dHU);
+    o.D[2][0] = T * k.haptotaxis * s.Tau * s.fb;
+    o.A[2][1] = -T * src;
+    o.A[2][2] = 1.0 - T * (src + s.lambda_RT * s.Tau * s.Lom_dfb + s.omicro_RT * s.Tau * s.Ome_dfb - k.omega);
+    {
+      const double b0 = T * k.diffusion * s.dTau, b1 = T * k.haptotaxis * s.dTau * s.fb,
+                   b2 = T * k.radiotaxis * s.dTau * s.fb;
+      o.B[2][1][0] = b0; o.B[2][1][1] = b1; o.B[2][1][2] = b2;
+      o.B[2][2][0] = b0;
+      o.B[2][2][1] = b1 + T * k.haptotaxis * s.Tau;
+      o.B[2][2][2] = b2 + T * k.radiotaxis * s.Tau;
+    }
+    o.D[2][2] = T * k.diffusion * s.Tau;
+  }
+};
+
+// =========================================================================================
+// HCC: unknowns (l, c, n); gradient field 0 = c.  GRAD_sigma == 0 (src/coupled_hcc.C:508), so
+// every mechano term vanishes and is omitted.  Quirks kept: spurious capacity term in blocks
+// [0][1],[0][2],[1][0]; the d/dn block of the c equation lands in [1][1] (App. D.1-2).
+// =========================================================================================
+struct HccK {
+  double DT2, Lambda, Kappa, ek, prod_l, dif_c, prod_c, nec_l, nec_c;
+};
+
+struct Hcc {
+  static constexpr int NV = 3, NG = 1, NAUX = 0;
+  using K = HccK;
+  using C = Coef<NV, NG>;
+  RDC_HD static constexpr int grad_src(int) { return 1; }
+  RDC_HD static constexpr bool hasA(int a, int b) { return !(a == 1 && b == 2); }
+  RDC_HD static constexpr bool hasB(int a, int b, int) { return a == 1 && b <= 1; }
+  RDC_HD static constexpr bool hasD(int a, int b) { return a == 1 && b == 1; }
+  RDC_HD static constexpr bool hasRG(int a, int) { return a == 1; }
+
+  static inline K derive(const rdc_hcc_params& p) {
+    K k;
+    k.DT2 = p.time_step / 2.0;
+    k.Lambda = p.cells_min_capacity;
+    k.Kappa = p.cells_max_capacity;
+    k.ek = p.cells_max_capacity_exponent;
+    k.prod_l = p.produce_l; k.dif_c = p.diffuse_c; k.prod_c = p.produce_c;
+    k.nec_l = p.necrosis_l / k.Kappa;  // :459-460
+    k.nec_c = p.necrosis_c / k.Kappa;
+    return k;
+  }
+  static inline double exponent(const K& k) { return k.ek; }
+
+  struct Pt { double l, c, n, Tau, dT, dif_c; };
+
+  template <int EXP_MODE>
+  RDC_HD static void point(const K& k, const double* u, const double* /*aux*/, Pt& s) {
+    s.l = u[0]; s.c = u[1]; s.n = u[2];
+    const double Te = (s.l + s.c + s.n) / k.Kappa;  // :513
+    if (Te <= 0.0) { s.Tau = 1.0; s.dT = 0.0; }
+    else if (Te >= 1.0) { s.Tau = 0.0; s.dT = 0.0; }
+    else {
+      double p, pm1;
+      pow_pair<EXP_MODE>(1.0 - Te, k.ek, p, pm1);
+      s.Tau = p;
+      s.dT = (-k.ek / k.Kappa) * pm1;
+    }
+    s.dif_c = (s.c > k.Lambda ? k.dif_c : 0.0);  // :534
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    const double pl = k.prod_l * s.dT * s.l, pc = k.prod_c * s.dT * s.c;
+    o.R[0] = s.l + T * (k.prod_l * s.Tau * s.l - k.nec_l * s.l * s.n);               // :540-546
+    o.A[0][0] = 1.0 - T * (k.prod_l * s.Tau + pl - k.nec_l * s.n);                   // :569-576
+    o.A[0][1] = 1.0 - T * pl;                                                        // :577-582
+    o.A[0][2] = 1.0 - T * (pl - k.nec_l * s.l);                                      // :583-589
+    o.R[1] = s.c + T * (k.prod_c * s.Tau * s.c - k.nec_c * s.c * s.n);               // :548-556
+    o.RG[1][0] = -T * s.dif_c * s.Tau;
+    o.A[1][0] = 1.0 - T * pc;                                                        // :591-598
+    o.B[1][0][0] = T * s.dif_c * s.dT;
+    o.A[1][1] = (1.0 - T * (k.prod_c * s.Tau + pc - k.nec_c * s.n))                  // :599-610
+              + (1.0 - T * (pc - k.nec_c * s.c));                                    // :611-619
+    o.B[1][1][0] = 2.0 * (T * s.dif_c * s.dT);
+    o.D[1][1] = T * s.dif_c * s.Tau;
+    o.R[2] = s.n + T * (k.nec_l * s.l * s.n + k.nec_c * s.c * s.n);                  // :558-564
+    o.A[2][0] = -T * k.nec_l * s.n;                                                  // :621-625
+    o.A[2][1] = -T * k.nec_c * s.n;                                                  // :626-630
+    o.A[2][2] = 1.0 - T * (k.nec_l * s.l + k.nec_c * s.c);                           // :631-637
+  }
+};
+
+// exponent -> EXP_MODE (0 = general pow)
+static inline int exp_mode_of(double e) {
+  if (e == 1.0) return 1;
+  if (e == 2.0) return 2;
+  if (e == 3.0) return 3;
+  if (e == 4.0) return 4;
+  return 0;
+}
+
+}  // namespace rdc
+#endif

@@ -1,0 +1,40 @@
+// rdc_internal.h — context object and host-side mesh preparation shared by the C-ABI
+// translation units.  Not installed; the public surface is include/rdc_assembly.h.
+#ifndef RDC_INTERNAL_H
+#define RDC_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "rdc_kernels.h"
+#include "rdc_prep.h"
+
+namespace rdc {
+
+// ---- kernel launch plumbing -----------------------------------------------------------------
+struct LaunchArgs {
+  MeshDev m;
+  int nen, exp_mode, strategy;
+  const double* u;
+  const double* aux;
+  double* packed;  // scratch for the per-node records of the TET4 fast path
+  int variant;     // RDC_VARIANT_*
+  double* val;
+  double* rhs;
+  hipStream_t stream;
+  const int64_t* colour_ptr;  // host
+  int n_colours;
+  int n_wg;
+  size_t lds_bytes;
+};
+
+template <class M>
+hipError_t launch_rd(const LaunchArgs& a, const typename M::K& k);
+// TET4-specialised factored kernels (rdc_tet4_fast.hip)
+template <class M>
+hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k);
+
+}  // namespace rdc
+#endif

@@ -1,0 +1,168 @@
+// rdc_kernels.h — generic (any model x TET4/HEX8) HIP kernels of the assembly path.
+//
+//   rd_row           one row-node of the element matrices, all quadrature points   (device fn)
+//   k_coloured       element-parallel, one launch per colour, plain RMW, no atomics
+//   k_rowgather      row-owner gather: a workgroup owns a run of consecutive nodes, accumulates
+//                    their complete CSR rows in LDS and streams them out once
+//
+// The reference loop these replace: src/pihna.C:383-756 (and its ripf / coupled_hcc twins).
+#ifndef RDC_KERNELS_H
+#define RDC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rdc_row.h"
+
+namespace rdc {
+
+// device view of the mesh / pattern (all pointers device memory)
+struct MeshDev {
+  int64_t n_elem, n_node, n_owned;
+  const uint32_t* conn;       // [n_elem][NEN]
+  const double* xyz;          // [n_node][3]
+  const int64_t* bptr;        // [n_owned+1] node-block row pointer
+  const uint16_t* eslot;      // [n_elem][NEN*NEN] slot of node j in the row of node i
+  // coloured scatter
+  const uint32_t* elem_order; // elements sorted by colour
+  const uint64_t* first_mask; // [n_elem] bit (i*NEN+j): this element is the first writer of block (i,j)
+  const uint8_t* first_rhs;   // [n_elem] bit i: first writer of the rhs entries of node i
+  // row gather
+  const uint32_t* pair_elem;  // [n_pairs] incident element of a (node, element) pair, grouped by node
+  const uint8_t* pair_local;  // [n_pairs] local index of the node inside that element
+  const int64_t* node_pair_ptr;  // [n_owned+1]
+  const int32_t* wg_node_ptr;    // [n_wg+1] consecutive owned nodes per workgroup
+};
+
+template <class M, int NEN>
+__device__ __forceinline__ void load_element(const MeshDev& m, int64_t e, const double* __restrict__ u,
+                                             const double* __restrict__ aux, uint32_t (&nd)[NEN],
+                                             double (&X)[NEN][3], double (&U)[NEN][M::NV],
+                                             double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1]) {
+#pragma unroll
+  for (int i = 0; i < NEN; i++) nd[i] = m.conn[e * NEN + i];
+#pragma unroll
+  for (int i = 0; i < NEN; i++) {
+    const int64_t n = nd[i];
+#pragma unroll
+    for (int d = 0; d < 3; d++) X[i][d] = m.xyz[3 * n + d];
+#pragma unroll
+    for (int v = 0; v < M::NV; v++) U[i][v] = u[n * M::NV + v];
+    if (M::NAUX > 0) {
+#pragma unroll
+      for (int v = 0; v < M::NAUX; v++) AX[i][v] = aux[n * M::NAUX + v];
+    } else {
+      AX[i][0] = 0.0;
+    }
+  }
+}
+
+// ---- coloured scatter: elements [first, first+count) of elem_order share no node ----------
+template <class M, int NEN, int EXP_MODE>
+__global__ void __launch_bounds__(256)
+k_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count,
+           const double* __restrict__ u, const double* __restrict__ aux, double* __restrict__ val,
+           double* __restrict__ rhs) {
+  constexpr int NV = M::NV;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const int64_t e = m.elem_order[first + t];
+  uint32_t nd[NEN];
+  double X[NEN][3], U[NEN][NV], AX[NEN][M::NAUX > 0 ? M::NAUX : 1];
+  load_element<M, NEN>(m, e, u, aux, nd, X, U, AX);
+  const uint64_t fm = m.first_mask[e];
+  const uint32_t fr = m.first_rhs[e];
+#pragma unroll 1
+  for (int i = 0; i < NEN; i++) {
+    const int64_t I = m.conn[e * NEN + i];
+    if (I >= m.n_owned) continue;  // row assembled by the owner partition
+    double acc[NV][NV][NEN], fe[NV];
+    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe);
+    const int64_t b0 = m.bptr[I];
+    const int64_t len = m.bptr[I + 1] - b0;
+    double* row = val + (int64_t)NV * NV * b0;
+#pragma unroll
+    for (int j = 0; j < NEN; j++) {
+      const int64_t s = m.eslot[e * (NEN * NEN) + i * NEN + j];
+      const bool first_writer = (fm >> (i * NEN + j)) & 1ull;
+#pragma unroll
+      for (int a = 0; a < NV; a++)
+#pragma unroll
+        for (int b = 0; b < NV; b++) {
+          double* p = row + a * NV * len + NV * s + b;
+          *p = first_writer ? acc[a][b][j] : (*p + acc[a][b][j]);
+        }
+    }
+    const bool first_r = (fr >> i) & 1u;
+#pragma unroll
+    for (int a = 0; a < NV; a++) {
+      double* p = rhs + I * NV + a;
+      *p = first_r ? fe[a] : (*p + fe[a]);
+    }
+  }
+}
+
+// ---- row gather ---------------------------------------------------------------------------
+// One workgroup owns the consecutive owned nodes [wg_node_ptr[w], wg_node_ptr[w+1]); their CSR
+// rows form ONE contiguous slice of val[].  One thread per (node, incident element) pair
+// evaluates the node's row of that element and adds it into the slice held in LDS; the slice is
+// then written once with coalesced streaming stores.  Every HBM byte of the matrix is written
+// exactly once, nothing is read back, no global atomics, no colours.
+template <class M, int NEN, int EXP_MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u,
+            const double* __restrict__ aux, double* __restrict__ val, double* __restrict__ rhs) {
+  constexpr int NV = M::NV;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int w = blockIdx.x;
+  const int64_t n0 = m.wg_node_ptr[w], n1 = m.wg_node_ptr[w + 1];
+  const int64_t vb0 = (int64_t)NV * NV * m.bptr[n0];
+  const int nval = (int)((int64_t)NV * NV * m.bptr[n1] - vb0);
+  const int nrhs = (int)(n1 - n0) * NV;
+  double* lrhs = lds + nval;
+  for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
+  __syncthreads();
+  const int64_t p0 = m.node_pair_ptr[n0], p1 = m.node_pair_ptr[n1];
+  for (int64_t p = p0 + threadIdx.x; p < p1; p += BLOCK) {
+    const int64_t e = m.pair_elem[p];
+    const int i = m.pair_local[p];
+    uint32_t nd[NEN];
+    double X[NEN][3], U[NEN][NV], AX[NEN][M::NAUX > 0 ? M::NAUX : 1];
+    load_element<M, NEN>(m, e, u, aux, nd, X, U, AX);
+    double acc[NV][NV][NEN], fe[NV];
+    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe);
+    const int64_t I = m.conn[e * NEN + i];
+    const int64_t b0 = m.bptr[I];
+    const int len = (int)(m.bptr[I + 1] - b0);
+    double* row = lds + ((int64_t)NV * NV * b0 - vb0);
+#pragma unroll
+    for (int j = 0; j < NEN; j++) {
+      const int s = m.eslot[e * (NEN * NEN) + i * NEN + j];
+#pragma unroll
+      for (int a = 0; a < NV; a++)
+#pragma unroll
+        for (int b = 0; b < NV; b++)
+          __hip_atomic_fetch_add(row + a * NV * len + NV * s + b, acc[a][b][j], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int a = 0; a < NV; a++)
+      __hip_atomic_fetch_add(lrhs + (I - n0) * NV + a, fe[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  double* out = val + vb0;
+  for (int x = threadIdx.x; x < nval; x += BLOCK) out[x] = lds[x];
+  double* orhs = rhs + n0 * NV;
+  for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
+}
+
+// check_solution clamp (src/pihna.C:785-790), in place
+static __global__ void k_clamp_nonnegative(double* __restrict__ u, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double x = u[i];
+    if (x < 0.0) u[i] = 0.0;
+  }
+}
+
+}  // namespace rdc
+#endif

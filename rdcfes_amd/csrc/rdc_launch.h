@@ -1,0 +1,42 @@
+// rdc_launch.h — dispatch of the generic kernels on (element type, exponent mode, strategy).
+// Included by one translation unit per model so the models compile in parallel.
+#ifndef RDC_LAUNCH_H
+#define RDC_LAUNCH_H
+#include "rdc_internal.h"
+
+namespace rdc {
+
+template <class M, int NEN, int EXP_MODE>
+static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
+  if (a.strategy == RDC_SCATTER_ROWGATHER) {
+    constexpr int BLOCK = 256;
+    if (a.n_wg > 0)
+      hipLaunchKernelGGL((k_rowgather<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), a.lds_bytes,
+                         a.stream, a.m, k, a.u, a.aux, a.val, a.rhs);
+    return hipGetLastError();
+  }
+  // coloured: one launch per colour, stream order is the only synchronisation needed
+  for (int c = 0; c < a.n_colours; c++) {
+    const int64_t first = a.colour_ptr[c], count = a.colour_ptr[c + 1] - first;
+    if (count <= 0) continue;
+    const int block = 256;
+    const int64_t grid = (count + block - 1) / block;
+    hipLaunchKernelGGL((k_coloured<M, NEN, EXP_MODE>), dim3((unsigned)grid), dim3(block), 0, a.stream, a.m, k,
+                       first, count, a.u, a.aux, a.val, a.rhs);
+  }
+  return hipGetLastError();
+}
+
+template <class M>
+hipError_t launch_rd(const LaunchArgs& a, const typename M::K& k) {
+  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC) return launch_tet4_fast<M>(a, k);
+  if (a.nen == 4) {
+    if (a.exp_mode == 3) return launch_rd_impl<M, 4, 3>(a, k);
+    return launch_rd_impl<M, 4, 0>(a, k);
+  }
+  if (a.exp_mode == 3) return launch_rd_impl<M, 8, 3>(a, k);
+  return launch_rd_impl<M, 8, 0>(a, k);
+}
+
+}  // namespace rdc
+#endif

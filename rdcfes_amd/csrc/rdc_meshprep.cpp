@@ -1,0 +1,196 @@
+// rdc_meshprep.cpp — one-time host preparation of a mesh partition:
+//   * node-block CSR pattern of the owned rows (the sparsity libMesh's es.init() builds,
+//     src/pihna.C:48), dof = node*nvar + var
+//   * per-element slot map (where Ke(i,j) lands in row i) -- replaces MatSetValues' row search
+//   * greedy element colouring + first-writer masks (coloured scatter needs no memset, no atomics)
+//   * (node, incident element) pairs and workgroup ranges for the row-gather kernels
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "rdc_prep.h"
+
+namespace rdc {
+
+std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,
+                       int nvar, size_t lds_budget_bytes, int block, HostPrep& P) {
+  if (nen != 4 && nen != 8) return "element type must be TET4 (4) or HEX8 (8)";
+  if (n_elem < 0 || n_node <= 0 || n_owned < 0 || n_owned > n_node) return "bad mesh sizes";
+  if (n_node >= (int64_t)1 << 31) return "more than 2^31 local nodes not supported";
+  if (n_elem >= (int64_t)1 << 32) return "more than 2^32 local elements not supported";
+  if (nvar < 1 || nvar > 8) return "nvar must be in 1..8";
+  P = HostPrep();
+  P.nen = nen; P.nvar = nvar; P.n_elem = n_elem; P.n_node = n_node; P.n_owned = n_owned;
+  for (int64_t x = 0; x < n_elem * nen; x++)
+    if (conn[x] >= (uint64_t)n_node) return "connectivity entry out of range";
+  for (int64_t e = 0; e < n_elem; e++)
+    for (int i = 0; i < nen; i++)
+      for (int j = i + 1; j < nen; j++)
+        if (conn[e * nen + i] == conn[e * nen + j]) return "degenerate element (repeated node)";
+
+  // ---- node -> incident (element, local index) lists, counting sort ------------------------
+  std::vector<int64_t> inc_ptr((size_t)n_node + 1, 0);
+  for (int64_t x = 0; x < n_elem * nen; x++) inc_ptr[conn[x] + 1]++;
+  for (int64_t n = 0; n < n_node; n++) inc_ptr[n + 1] += inc_ptr[n];
+  std::vector<uint32_t> inc_elem((size_t)inc_ptr[n_node]);
+  std::vector<uint8_t> inc_loc((size_t)inc_ptr[n_node]);
+  {
+    std::vector<int64_t> fill(inc_ptr.begin(), inc_ptr.end() - 1);
+    for (int64_t e = 0; e < n_elem; e++)
+      for (int i = 0; i < nen; i++) {
+        const int64_t n = conn[e * nen + i];
+        inc_elem[fill[n]] = (uint32_t)e;
+        inc_loc[fill[n]] = (uint8_t)i;
+        fill[n]++;
+      }
+  }
+
+  // ---- node-block pattern of the owned rows -------------------------------------------------
+  P.bptr.assign((size_t)n_owned + 1, 0);
+  {
+    std::vector<int64_t> len((size_t)n_owned, 0);
+#pragma omp parallel
+    {
+      std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 4096)
+      for (int64_t n = 0; n < n_owned; n++) {
+        tmp.clear();
+        tmp.push_back((int32_t)n);
+        for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
+          const uint32_t* c = conn + (int64_t)inc_elem[k] * nen;
+          for (int i = 0; i < nen; i++) tmp.push_back((int32_t)c[i]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        len[n] = std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+      }
+    }
+    for (int64_t n = 0; n < n_owned; n++) P.bptr[n + 1] = P.bptr[n] + len[n];
+    P.bcol.resize((size_t)P.bptr[n_owned]);
+#pragma omp parallel
+    {
+      std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 4096)
+      for (int64_t n = 0; n < n_owned; n++) {
+        tmp.clear();
+        tmp.push_back((int32_t)n);
+        for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
+          const uint32_t* c = conn + (int64_t)inc_elem[k] * nen;
+          for (int i = 0; i < nen; i++) tmp.push_back((int32_t)c[i]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        std::copy(tmp.begin(), tmp.end(), P.bcol.begin() + P.bptr[n]);
+      }
+    }
+  }
+  int64_t max_len = 0;
+  for (int64_t n = 0; n < n_owned; n++) max_len = std::max(max_len, P.bptr[n + 1] - P.bptr[n]);
+  if (max_len >= 0xFFFF) return "node valence too large for 16-bit slot map";
+  if ((int64_t)nvar * nvar * P.bptr[n_owned] >= ((int64_t)1 << 40)) return "matrix too large";
+
+  // ---- slot map ----------------------------------------------------------------------------
+  P.eslot.assign((size_t)n_elem * nen * nen, 0xFFFF);
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < n_elem; e++) {
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++) {
+      const int64_t I = c[i];
+      if (I >= n_owned) continue;
+      const int32_t* b = P.bcol.data() + P.bptr[I];
+      const int32_t* be = P.bcol.data() + P.bptr[I + 1];
+      for (int j = 0; j < nen; j++) {
+        const int32_t* it = std::lower_bound(b, be, (int32_t)c[j]);
+        P.eslot[(size_t)e * nen * nen + i * nen + j] = (uint16_t)(it - b);
+      }
+    }
+  }
+
+  // ---- greedy colouring: elements of one colour share no node ----------------------------
+  {
+    constexpr int W = 4;  // up to 256 colours
+    std::vector<uint64_t> used((size_t)n_node * W, 0);
+    P.colour.assign((size_t)n_elem, -1);
+    int ncol = 0;
+    for (int64_t e = 0; e < n_elem; e++) {
+      const uint32_t* c = conn + e * nen;
+      uint64_t m[W] = {0, 0, 0, 0};
+      for (int i = 0; i < nen; i++)
+        for (int w = 0; w < W; w++) m[w] |= used[(size_t)c[i] * W + w];
+      int col = -1;
+      for (int w = 0; w < W && col < 0; w++)
+        if (~m[w]) col = w * 64 + __builtin_ctzll(~m[w]);
+      if (col < 0) return "mesh needs more than 256 colours";
+      P.colour[e] = col;
+      ncol = std::max(ncol, col + 1);
+      for (int i = 0; i < nen; i++) used[(size_t)c[i] * W + (col >> 6)] |= 1ull << (col & 63);
+    }
+    P.n_colours = ncol;
+    P.colour_ptr.assign((size_t)ncol + 1, 0);
+    for (int64_t e = 0; e < n_elem; e++) P.colour_ptr[P.colour[e] + 1]++;
+    for (int c = 0; c < ncol; c++) P.colour_ptr[c + 1] += P.colour_ptr[c];
+    P.elem_order.resize((size_t)n_elem);
+    std::vector<int64_t> fill(P.colour_ptr.begin(), P.colour_ptr.end() - 1);
+    for (int64_t e = 0; e < n_elem; e++) P.elem_order[fill[P.colour[e]]++] = (uint32_t)e;
+  }
+
+  // ---- first-writer masks in colour order --------------------------------------------------
+  {
+    P.first_mask.assign((size_t)n_elem, 0);
+    P.first_rhs.assign((size_t)n_elem, 0);
+    std::vector<uint8_t> touched((size_t)P.bptr[n_owned], 0), touched_r((size_t)n_owned, 0);
+    for (int64_t x = 0; x < n_elem; x++) {
+      const int64_t e = P.elem_order[x];
+      const uint32_t* c = conn + e * nen;
+      uint64_t fm = 0;
+      uint8_t fr = 0;
+      for (int i = 0; i < nen; i++) {
+        const int64_t I = c[i];
+        if (I >= n_owned) continue;
+        if (!touched_r[I]) { touched_r[I] = 1; fr |= (uint8_t)(1u << i); }
+        for (int j = 0; j < nen; j++) {
+          const int64_t pos = P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + j];
+          if (!touched[pos]) { touched[pos] = 1; fm |= 1ull << (i * nen + j); }
+        }
+      }
+      P.first_mask[e] = fm;
+      P.first_rhs[e] = fr;
+    }
+    // every owned row must be reached by at least one element, or it would stay unwritten
+    for (int64_t n = 0; n < n_owned; n++)
+      if (!touched_r[n]) return "owned node without any incident element";
+  }
+
+  // ---- row-gather pairs and workgroup ranges ------------------------------------------------
+  {
+    P.node_pair_ptr.assign((size_t)n_owned + 1, 0);
+    for (int64_t n = 0; n < n_owned; n++) P.node_pair_ptr[n + 1] = inc_ptr[n + 1];  // owned nodes come first
+    const int64_t npairs = inc_ptr[n_owned];
+    P.pair_elem.assign(inc_elem.begin(), inc_elem.begin() + npairs);
+    P.pair_local.assign(inc_loc.begin(), inc_loc.begin() + npairs);
+    P.rg_block = block;
+    P.rowgather_ok = true;
+    P.wg_node_ptr.clear();
+    P.wg_node_ptr.push_back(0);
+    int64_t pairs = 0;
+    size_t bytes = 0, max_bytes = 0;
+    for (int64_t n = 0; n < n_owned; n++) {
+      const int64_t np = inc_ptr[n + 1] - inc_ptr[n];
+      const size_t nb = sizeof(double) * ((size_t)nvar * nvar * (P.bptr[n + 1] - P.bptr[n]) + nvar);
+      if (nb > lds_budget_bytes) { P.rowgather_ok = false; break; }
+      if (n > P.wg_node_ptr.back() && (pairs + np > block || bytes + nb > lds_budget_bytes)) {
+        P.wg_node_ptr.push_back((int32_t)n);
+        pairs = 0;
+        bytes = 0;
+      }
+      pairs += np;
+      bytes += nb;
+      max_bytes = std::max(max_bytes, bytes);
+    }
+    P.wg_node_ptr.push_back((int32_t)n_owned);
+    P.rg_lds_bytes = max_bytes;
+    if (!P.rowgather_ok) { P.wg_node_ptr.assign(2, 0); P.wg_node_ptr[1] = 0; }
+  }
+  return std::string();
+}
+
+}  // namespace rdc

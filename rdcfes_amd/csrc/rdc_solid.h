@@ -1,0 +1,27 @@
+// rdc_solid.h — launch interface of the SolidSystem kernels (rdc_solid.hip).
+#ifndef RDC_SOLID_H
+#define RDC_SOLID_H
+#include "rdc_internal.h"
+namespace rdc {
+struct SolidArgs {
+  MeshDev m;
+  int nen;
+  const double* Xu;            // undeformed coordinates [n_node][3]
+  const double* fibre;         // [n_elem][3]
+  const int32_t* elem_material;
+  const rdc_solid_material* materials;
+  int64_t n_sides;
+  const int64_t* side_elem;
+  const int32_t* side_id;
+  const double* side_disp;
+  rdc_solid_params params;
+  int request_jacobian;
+  double* val;
+  double* rhs;
+  hipStream_t stream;
+  const int64_t* colour_ptr;   // host
+  int n_colours;
+};
+hipError_t launch_solid(const SolidArgs& a);
+}  // namespace rdc
+#endif

@@ -1,0 +1,115 @@
+"""ctypes mirrors of the POD parameter structs in include/rdc_assembly.h, plus constructors from the
+reference's string-keyed parameter names (the keys ``es.parameters.get<Real>(...)`` reads:
+src/pihna.C:358-381, src/ripf.C:377-408, src/coupled_hcc.C:450-461)."""
+from __future__ import annotations
+
+import ctypes as C
+
+_D = C.c_double
+
+
+class PihnaParams(C.Structure):
+    _fields_ = [(n, _D) for n in (
+        "time_step", "cells_min_capacity", "cells_max_capacity", "cytokines_max_capacity",
+        "cells_max_capacity_exponent", "necrosis_c", "necrosis_h", "necrosis_v", "diffuse_c", "taxis_c",
+        "diffuse_h", "taxis_h", "produce_c", "switch_c2h", "switch_h2c", "switch_h2n", "diffuse_v",
+        "taxis_v", "produce_v", "secrete_a_c", "secrete_a_h", "uptake_a_v", "decay_a")]
+
+
+class RipfParams(C.Structure):
+    _fields_ = [(n, _D) for n in (
+        "time_step", "VolFr_stroma", "VolFr_parenchyma", "VolFr_exponent", "VolFr_min_vacant",
+        "VolFr_max_vacant", "phi_cc_B", "phi_cc_D", "phi_cc", "phi_fb_B", "phi_fb_D", "phi_fb", "phi_tol",
+        "kappa", "kappa_RT_c", "delta", "delta_RT_a", "delta_RT_b", "lambda_", "lambda_RT_r", "lambda_HU_r",
+        "omicro", "omicro_RT_r", "omicro_fb_b", "omega", "diffusion", "haptotaxis", "radiotaxis")] + [
+        ("RT_dose_total_max", C.c_int32), ("_pad", C.c_int32)]
+
+
+class HccParams(C.Structure):
+    _fields_ = [(n, _D) for n in (
+        "time_step", "cells_min_capacity", "cells_max_capacity", "cells_max_capacity_exponent", "produce_l",
+        "diffuse_c", "mechano_c", "produce_c", "necrosis_l", "necrosis_c", "necrosis_pressure")]
+
+
+class SolidMaterial(C.Structure):
+    _fields_ = [("Young", _D), ("Poisson", _D), ("FibreStiffness", _D), ("rate", _D * 3)]
+
+
+class SolidParams(C.Structure):
+    _fields_ = [("pseudo_time", _D), ("displacement_penalty", _D), ("use_symmetry", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+# reference parameter key -> struct field
+PIHNA_KEYS = {
+    "time_step": "time_step",
+    "cells_min_capacity": "cells_min_capacity",
+    "cells_max_capacity": "cells_max_capacity",
+    "cytokines_max_capacity": "cytokines_max_capacity",
+    "cells_max_capacity/exponent": "cells_max_capacity_exponent",
+    "necrosis/c": "necrosis_c", "necrosis/h": "necrosis_h", "necrosis/v": "necrosis_v",
+    "diffuse/c": "diffuse_c", "taxis/c": "taxis_c", "diffuse/h": "diffuse_h", "taxis/h": "taxis_h",
+    "produce/c": "produce_c", "switch/c/to/h": "switch_c2h", "switch/h/to/c": "switch_h2c",
+    "switch/h/to/n": "switch_h2n", "diffuse/v": "diffuse_v", "taxis/v": "taxis_v", "produce/v": "produce_v",
+    "secrete/a/from/c": "secrete_a_c", "secrete/a/from/h": "secrete_a_h", "uptake/a/from/v": "uptake_a_v",
+    "decay/a": "decay_a",
+}
+# defaults of input(), src/pihna.C:139-235
+PIHNA_DEFAULTS = {k: 0.0 for k in PIHNA_KEYS}
+PIHNA_DEFAULTS.update({"time_step": 1.0e-9, "cells_min_capacity": 0.0, "cells_max_capacity": 1.0,
+                       "cytokines_max_capacity": 1.0, "cells_max_capacity/exponent": 1.0})
+
+RIPF_KEYS = {
+    "time_step": "time_step",
+    "volume_fraction/stroma": "VolFr_stroma", "volume_fraction/parenchyma": "VolFr_parenchyma",
+    "volume_fraction/exponent": "VolFr_exponent", "volume_fraction/min_vacant": "VolFr_min_vacant",
+    "volume_fraction/max_vacant": "VolFr_max_vacant",
+    "HU/phi/cc/build": "phi_cc_B", "HU/phi/cc/decay": "phi_cc_D", "HU/phi/cc/rate": "phi_cc",
+    "HU/phi/fb/build": "phi_fb_B", "HU/phi/fb/decay": "phi_fb_D", "HU/phi/fb/rate": "phi_fb",
+    "HU/phi/tolerance": "phi_tol",
+    "cc/kappa": "kappa", "cc/kappa/RT/c": "kappa_RT_c", "cc/delta": "delta", "cc/delta/RT/a": "delta_RT_a",
+    "cc/delta/RT/b": "delta_RT_b",
+    "fb/lambda": "lambda_", "fb/lambda/RT/r": "lambda_RT_r", "fb/lambda/HU/r": "lambda_HU_r",
+    "fb/omicro": "omicro", "fb/omicro/RT/r": "omicro_RT_r", "fb/omicro/fb/b": "omicro_fb_b",
+    "fb/omega": "omega", "fb/diffusion": "diffusion", "fb/haptotaxis": "haptotaxis",
+    "fb/radiotaxis": "radiotaxis", "RT_dose/total/max": "RT_dose_total_max",
+}
+# defaults of input(), src/ripf.C:172-249
+RIPF_DEFAULTS = {k: 0.0 for k in RIPF_KEYS}
+RIPF_DEFAULTS.update({"time_step": 1.0e-9, "volume_fraction/exponent": 1.0, "volume_fraction/min_vacant": 1.0e-12,
+                      "fb/lambda/HU/r": -1.0, "RT_dose/total/max": 0})
+
+HCC_KEYS = {
+    "time_step": "time_step", "cells/min_capacity": "cells_min_capacity", "cells/max_capacity": "cells_max_capacity",
+    "cells/max_capacity/exponent": "cells_max_capacity_exponent", "produce/l": "produce_l",
+    "diffuse/c": "diffuse_c", "mechano/c": "mechano_c", "produce/c": "produce_c", "necrosis/l": "necrosis_l",
+    "necrosis/c": "necrosis_c", "necrosis/pressure": "necrosis_pressure",
+}
+HCC_DEFAULTS = {k: 0.0 for k in HCC_KEYS}
+HCC_DEFAULTS.update({"time_step": 1.0e-9, "cells/max_capacity": 1.0, "cells/max_capacity/exponent": 1.0})
+
+
+def _from_dict(cls, keys, defaults, d):
+    unknown = set(d) - set(keys)
+    if unknown:
+        raise KeyError(f"unknown parameter key(s) for {cls.__name__}: {sorted(unknown)}")
+    p = cls()
+    for k, f in keys.items():
+        v = d.get(k, defaults[k])
+        setattr(p, f, int(v) if f == "RT_dose_total_max" else float(v))
+    return p
+
+
+def pihna_params_from_dict(d):
+    return _from_dict(PihnaParams, PIHNA_KEYS, PIHNA_DEFAULTS, d)
+
+
+def ripf_params_from_dict(d):
+    p = _from_dict(RipfParams, RIPF_KEYS, RIPF_DEFAULTS, d)
+    if "volume_fraction/max_vacant" not in d:  # src/ripf.C:180-182: default 1 - min_vacant
+        p.VolFr_max_vacant = 1.0 - p.VolFr_min_vacant
+    return p
+
+
+def hcc_params_from_dict(d):
+    return _from_dict(HccParams, HCC_KEYS, HCC_DEFAULTS, d)

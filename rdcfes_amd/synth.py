@@ -1,0 +1,212 @@
+"""Synthetic meshes, fields and parameter sets — the large meshes of the reference's
+examples are not in its checkout (.MISSING_LARGE_BLOBS), so every benchmark / parity input is built
+here, seeded and reproducible.
+
+  K(n): unit cube, n^3 cells, 6 Kuhn tets per cell (positively oriented for libMesh's TET4 map)
+  H(n): unit cube, n^3 HEX8 cells
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+SEED = 20241016
+
+
+def _grid_nodes(n, jitter, rng):
+    g = np.arange(n + 1, dtype=np.float64) / n
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")  # node id = (k*(n+1) + j)*(n+1) + i, x fastest
+    xyz = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1)
+    if jitter > 0:
+        h = 1.0 / n
+        interior = np.all((xyz > 1e-12) & (xyz < 1 - 1e-12), axis=1)
+        d = rng.uniform(-jitter * h, jitter * h, size=xyz.shape)
+        xyz[interior] += d[interior]
+    return xyz
+
+
+def _cell_corner_ids(n):
+    c = np.arange(n, dtype=np.int64)
+    k, j, i = np.meshgrid(c, c, c, indexing="ij")
+    base = ((k * (n + 1) + j) * (n + 1) + i).ravel()
+
+    def corner(dx, dy, dz):
+        return base + (dz * (n + 1) + dy) * (n + 1) + dx
+
+    return corner
+
+
+def kuhn_tet_mesh(n, jitter=0.2, seed=SEED, order="lex"):
+    """K(n): returns (conn uint32 [6n^3][4], xyz float64 [(n+1)^3][3])."""
+    rng = np.random.default_rng(seed)
+    xyz = _grid_nodes(n, jitter, rng)
+    corner = _cell_corner_ids(n)
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        v = [np.zeros(3, dtype=int)]
+        for ax in perm:
+            w = v[-1].copy()
+            w[ax] = 1
+            v.append(w)
+        ids = [corner(*p) for p in v]
+        # parity of the permutation = orientation of (e_a, e_b, e_c)
+        inv = sum(1 for a in range(3) for b in range(a + 1, 3) if perm[a] > perm[b])
+        if inv % 2 == 1:
+            ids[2], ids[3] = ids[3], ids[2]
+        tets.append(np.stack(ids, axis=1))
+    conn = np.stack(tets, axis=1).reshape(-1, 4)  # the 6 tets of a cell are adjacent
+    return _reorder(conn, xyz, order, rng)
+
+
+def hex_mesh(n, jitter=0.0, seed=SEED, order="lex"):
+    """H(n): returns (conn uint32 [n^3][8], xyz) in libMesh/Gmsh HEX8 node order."""
+    rng = np.random.default_rng(seed)
+    xyz = _grid_nodes(n, jitter, rng)
+    corner = _cell_corner_ids(n)
+    order8 = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    conn = np.stack([corner(*p) for p in order8], axis=1)
+    return _reorder(conn, xyz, order, rng)
+
+
+def _reorder(conn, xyz, order, rng):
+    if order == "lex":
+        pass
+    elif order == "random":
+        pn = rng.permutation(xyz.shape[0])  # new id of old node
+        inv = np.empty_like(pn)
+        inv[pn] = np.arange(pn.size)
+        xyz = xyz[inv]
+        conn = pn[conn]
+        conn = conn[rng.permutation(conn.shape[0])]
+    else:
+        raise ValueError(f"unknown order {order!r}")
+    return np.ascontiguousarray(conn, dtype=np.uint32), np.ascontiguousarray(xyz)
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter sets (reference string keys)
+# ---------------------------------------------------------------------------------------------
+def pihna_param_dict(variant="shipped"):
+    """run/PIHNA/input.dat:9-49; 'full' turns on every transport term so no block is trivially 0."""
+    d = {
+        "time_step": 0.1, "cells_min_capacity": 1.0, "cells_max_capacity": 2.39e5,
+        "cells_max_capacity/exponent": 3.0, "cytokines_max_capacity": 1.0e-8,
+        "necrosis/c": 500.0, "necrosis/h": 200.0, "necrosis/v": 300.0,
+        "diffuse/c": 0.0, "taxis/c": 0.0, "diffuse/h": 0.0, "taxis/h": 0.0, "produce/c": -2.5,
+        "switch/c/to/h": 1.0, "switch/h/to/c": 1.82, "switch/h/to/n": 0.5,
+        "diffuse/v": 0.5, "taxis/v": 0.0, "produce/v": 10.0,
+        "secrete/a/from/c": 2.77e-13, "secrete/a/from/h": 5.22e-10, "uptake/a/from/v": 0.0, "decay/a": 5678.4,
+    }
+    if variant == "full":
+        d.update({"diffuse/c": 0.1, "taxis/c": 0.1, "diffuse/h": 0.1, "taxis/h": 0.1, "taxis/v": 0.1,
+                  "uptake/a/from/v": 1.0e-5})
+    elif variant == "realexp":  # non-integer crowding exponent -> general pow() path
+        d.update({"cells_max_capacity/exponent": 2.5, "diffuse/c": 0.1, "taxis/c": 0.1, "diffuse/h": 0.1,
+                  "taxis/h": 0.1, "taxis/v": 0.1, "uptake/a/from/v": 1.0e-5})
+    elif variant != "shipped":
+        raise ValueError(variant)
+    return d
+
+
+def ripf_param_dict(variant="shipped"):
+    """run/RIPF133/input.dat:8-36 (+ runtime RT_dose/total/max = 73)."""
+    d = {
+        "time_step": 0.1, "volume_fraction/stroma": 0.30, "volume_fraction/parenchyma": 0.20,
+        "volume_fraction/exponent": 2.5, "volume_fraction/min_vacant": 1.0e-5,
+        "HU/phi/tolerance": 1.0e-3, "cc/delta": 0.0864, "cc/delta/RT/a": 0.3, "cc/delta/RT/b": 0.03,
+        "fb/lambda": 0.01, "fb/lambda/RT/r": 1.0, "fb/omega": 0.1, "fb/diffusion": 1.0e-20,
+        "fb/haptotaxis": 0.05, "RT_dose/total/max": 73,
+    }
+    if variant == "full":
+        d.update({"HU/phi/cc/build": 0.3, "HU/phi/cc/decay": -0.2, "HU/phi/cc/rate": 0.05, "HU/phi/fb/build": 0.4,
+                  "HU/phi/fb/decay": -0.1, "HU/phi/fb/rate": 0.07, "cc/kappa": 0.01, "cc/kappa/RT/c": 0.02,
+                  "fb/lambda/RT/r": 0.0, "fb/lambda/HU/r": -600.0, "fb/omicro": 0.02, "fb/omicro/RT/r": 0.0,
+                  "fb/omicro/fb/b": 0.05, "fb/diffusion": 1.0e-3, "fb/radiotaxis": 0.03,
+                  "volume_fraction/exponent": 3.0})
+    elif variant != "shipped":
+        raise ValueError(variant)
+    return d
+
+
+def hcc_param_dict(variant="full"):
+    """run/Coupled/HCC/input.dat gives only the capacity keys (all rates default to 0); 'full' adds
+    non-zero rates so every touched block is exercised."""
+    d = {"time_step": 0.01, "cells/min_capacity": 0.0, "cells/max_capacity": 1.0, "cells/max_capacity/exponent": 3.0}
+    if variant == "full":
+        d.update({"produce/l": 0.8, "diffuse/c": 0.05, "mechano/c": 0.02, "produce/c": 1.2, "necrosis/l": 0.3,
+                  "necrosis/c": 0.4, "necrosis/pressure": 0.1})
+    elif variant != "shipped":
+        raise ValueError(variant)
+    return d
+
+
+# ---------------------------------------------------------------------------------------------
+# fields
+# ---------------------------------------------------------------------------------------------
+def pihna_fields(xyz, seed=SEED):
+    """[n_node][5] (n,c,h,v,a): background (0,0,0,7170,0) as run/PIHNA/Brain_Model_Initial_Nodal_Field.dat,
+    a non-degenerate tumour state inside a sphere r=0.25 (v > 0 everywhere: the 0/0 path of
+    src/pihna.C:477 is exercised separately)."""
+    rng = np.random.default_rng(seed + 1)
+    n = xyz.shape[0]
+    u = np.zeros((n, 5))
+    u[:, 3] = 7170.0
+    r = np.linalg.norm(xyz - 0.5, axis=1)
+    s = r < 0.25
+    k = int(s.sum())
+    u[s, 0] = rng.uniform(0, 5e2, k)
+    u[s, 1] = rng.uniform(0, 2e3, k)
+    u[s, 2] = rng.uniform(0, 2e3, k)
+    u[s, 3] = rng.uniform(3e3, 7.17e3, k)
+    u[s, 4] = rng.uniform(0, 1e-8, k)
+    return u
+
+
+def ripf_fields(xyz, seed=SEED):
+    """returns (u [n][3] = HU,cc,fb ; aux [n][3] = cc_dtime, fb_dtime, RT_total), mimicking
+    run/RIPF133/*.dat value ranges."""
+    rng = np.random.default_rng(seed + 2)
+    n = xyz.shape[0]
+    u = np.zeros((n, 3))
+    u[:, 0] = rng.uniform(-1019.0, 1094.0, n)
+    r2 = np.sum((xyz - np.array([0.45, 0.55, 0.5])) ** 2, axis=1)
+    s = r2 < 0.3 ** 2
+    k = int(s.sum())
+    u[s, 1] = rng.uniform(0, 1, k)
+    u[s, 2] = rng.uniform(0, 0.3, k)
+    aux = np.empty((n, 3))
+    aux[:, 0] = rng.uniform(-1e-2, 1e-2, n)
+    aux[:, 1] = rng.uniform(-1e-2, 1e-2, n)
+    aux[:, 2] = 67.0 * np.exp(-r2 / 0.1) + 6.7 * np.exp(-r2 / 0.01)
+    return u, aux
+
+
+def hcc_fields(xyz, seed=SEED):
+    rng = np.random.default_rng(seed + 3)
+    return rng.uniform(0.0, 0.3, (xyz.shape[0], 3))
+
+
+def solid_displacement(xyz, amp=0.02):
+    """smooth displacement field used to deform the mesh for cfg5-style tests."""
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    d = np.stack([np.sin(2 * np.pi * y) * np.cos(np.pi * z), np.sin(2 * np.pi * z) * np.cos(np.pi * x),
+                  np.sin(2 * np.pi * x) * np.cos(np.pi * y)], axis=1)
+    return amp * d
+
+
+def boundary_sides(elem_type, conn, xyz, axis, value, tol=1e-9):
+    """(elem, side) pairs whose side nodes all lie on the plane xyz[:,axis] == value.
+    Side numbering = libMesh Tet4/Hex8 side_nodes_map."""
+    if elem_type == 4:
+        sides = [(0, 2, 1), (0, 1, 3), (1, 2, 3), (2, 0, 3)]
+    else:
+        sides = [(0, 3, 2, 1), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7), (4, 5, 6, 7)]
+    on = np.abs(xyz[:, axis] - value) < tol
+    es, ss = [], []
+    for s, nodes in enumerate(sides):
+        m = np.all(on[conn[:, nodes]], axis=1)
+        idx = np.nonzero(m)[0]
+        es.append(idx)
+        ss.append(np.full(idx.size, s, dtype=np.int32))
+    return np.concatenate(es).astype(np.int64), np.concatenate(ss)

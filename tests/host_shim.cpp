@@ -1,0 +1,177 @@
+// host_shim.cpp — TEST-ONLY host build of the product's host/device headers, so the CPU suite
+// (-m "not gpu") can check the exact row-evaluation code the HIP kernels run, and the mesh
+// preparation, against the oracle without a GPU.  It is compiled by tests/conftest.py with g++
+// into tests/_build/ and is never part of librdc_assembly.so (the product has no CPU path).
+#include <cstring>
+#include <string>
+
+#include "../rdcfes_amd/csrc/rdc_prep.h"
+#include "../rdcfes_amd/csrc/rdc_row.h"
+#include "../rdcfes_amd/csrc/rdc_tet4_fast.h"
+
+using namespace rdc;
+
+namespace {
+
+template <class M, int NEN, int EM>
+void row_generic(const typename M::K& k, const double* Xp, const double* Up, const double* Ap, int irow, double* acc,
+                 double* fe) {
+  constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
+  double X[NEN][3], U[NEN][NV], AX[NEN][NA];
+  for (int i = 0; i < NEN; i++) {
+    for (int d = 0; d < 3; d++) X[i][d] = Xp[3 * i + d];
+    for (int v = 0; v < NV; v++) U[i][v] = Up[NV * i + v];
+    for (int v = 0; v < NA; v++) AX[i][v] = (M::NAUX > 0 && Ap) ? Ap[M::NAUX * i + v] : 0.0;
+  }
+  double a[NV][NV][NEN], f[NV];
+  rd_row<M, NEN, EM>(k, X, U, AX, irow, a, f);
+  std::memcpy(acc, a, sizeof(a));
+  std::memcpy(fe, f, sizeof(f));
+}
+
+template <class M>
+struct ArraySink {
+  double* acc;  // [NV][NV][4] in ORIGINAL column order
+  double* fe;
+  int irow;
+  void ke(int a, int b, int j, double v) { acc[(a * M::NV + b) * 4 + (j ^ irow)] = v; }
+  void fe_(int a, double v) { fe[a] = v; }
+};
+template <class M>
+struct ArraySinkAdapter {
+  ArraySink<M> s;
+  void ke(int a, int b, int j, double v) { s.ke(a, b, j, v); }
+  void fe(int a, double v) { s.fe_(a, v); }
+};
+
+template <class M, int EM>
+void row_fast(const typename M::K& k, const double* Xp, const double* Up, const double* Ap, int irow, double* acc,
+              double* fe) {
+  constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
+  double X[4][3], U[4][NV], AX[4][NA];
+  for (int j = 0; j < 4; j++) {  // rotate the row node to local 0: j -> j ^ irow (rdc_tet4_fast.h)
+    const int jo = j ^ irow;
+    for (int d = 0; d < 3; d++) X[j][d] = Xp[3 * jo + d];
+    for (int v = 0; v < NV; v++) U[j][v] = Up[NV * jo + v];
+    for (int v = 0; v < NA; v++) AX[j][v] = (M::NAUX > 0 && Ap) ? Ap[M::NAUX * jo + v] : 0.0;
+  }
+  ArraySinkAdapter<M> sink{{acc, fe, irow}};
+  tet4_row0<M, EM>(k, X, U, AX, sink);
+}
+
+template <class M, class P>
+int run(const P* p, int nen, int fast, int force_general_pow, const double* X, const double* U, const double* A,
+        int irow, double* acc, double* fe) {
+  const typename M::K k = M::derive(*p);
+  const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == 3;
+  if (fast) {
+    if (nen != 4) return 1;
+    if (cube) row_fast<M, 3>(k, X, U, A, irow, acc, fe); else row_fast<M, 0>(k, X, U, A, irow, acc, fe);
+    return 0;
+  }
+  if (nen == 4) {
+    if (cube) row_generic<M, 4, 3>(k, X, U, A, irow, acc, fe); else row_generic<M, 4, 0>(k, X, U, A, irow, acc, fe);
+  } else if (nen == 8) {
+    if (cube) row_generic<M, 8, 3>(k, X, U, A, irow, acc, fe); else row_generic<M, 8, 0>(k, X, U, A, irow, acc, fe);
+  } else return 1;
+  return 0;
+}
+
+template <class M, class P>
+int masks(const P* p, const double* u, const double* aux, double* worst) {
+  const typename M::K k = M::derive(*p);
+  typename M::Pt pt;
+  M::template point<0>(k, u, aux, pt);
+  typename M::C c;
+  M::coef(k, pt, c);
+  double w = 0.0;
+  for (int a = 0; a < M::NV; a++) {
+    for (int g = 0; g < M::NG; g++)
+      if (!M::hasRG(a, g) && c.RG[a][g] != 0.0) w = 1.0;
+    for (int b = 0; b < M::NV; b++) {
+      if (!M::hasA(a, b) && c.A[a][b] != 0.0) w = 1.0;
+      if (!M::hasD(a, b) && c.D[a][b] != 0.0) w = 1.0;
+      for (int g = 0; g < M::NG; g++)
+        if (!M::hasB(a, b, g) && c.B[a][b][g] != 0.0) w = 1.0;
+    }
+  }
+  *worst = w;
+  return 0;
+}
+
+HostPrep g_prep;
+std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+// model: 0 PIHNA, 1 RIPF, 2 HCC.  acc: [NV][NV][nen] (a, b, column node j in ORIGINAL local order)
+int shim_row(int model, int nen, int fast, int force_general_pow, const void* params, const double* X, const double* U,
+             const double* A, int irow, double* acc, double* fe) {
+  switch (model) {
+    case 0: return run<Pihna>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 1: return run<Ripf>((const rdc_ripf_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 2: return run<Hcc>((const rdc_hcc_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+  }
+  return 2;
+}
+
+// 1.0 in *worst if coef() produced a non-zero outside the structural masks
+int shim_masks(int model, const void* params, const double* u, const double* aux, double* worst) {
+  switch (model) {
+    case 0: return masks<Pihna>((const rdc_pihna_params*)params, u, aux, worst);
+    case 1: return masks<Ripf>((const rdc_ripf_params*)params, u, aux, worst);
+    case 2: return masks<Hcc>((const rdc_hcc_params*)params, u, aux, worst);
+  }
+  return 2;
+}
+
+// ---- mesh preparation ---------------------------------------------------------------------
+int shim_prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn, int nvar,
+                    int64_t lds_budget, int block) {
+  g_err = prep_build(nen, n_elem, n_node, n_owned, conn, nvar, (size_t)lds_budget, block, g_prep);
+  return g_err.empty() ? 0 : 1;
+}
+const char* shim_prep_error() { return g_err.c_str(); }
+int64_t shim_prep_size(int what) {
+  switch (what) {
+    case 0: return (int64_t)g_prep.bptr.size();
+    case 1: return (int64_t)g_prep.bcol.size();
+    case 2: return (int64_t)g_prep.eslot.size();
+    case 3: return (int64_t)g_prep.colour.size();
+    case 4: return (int64_t)g_prep.elem_order.size();
+    case 5: return (int64_t)g_prep.colour_ptr.size();
+    case 6: return (int64_t)g_prep.first_mask.size();
+    case 7: return (int64_t)g_prep.first_rhs.size();
+    case 8: return (int64_t)g_prep.pair_elem.size();
+    case 9: return (int64_t)g_prep.pair_local.size();
+    case 10: return (int64_t)g_prep.node_pair_ptr.size();
+    case 11: return (int64_t)g_prep.wg_node_ptr.size();
+    case 100: return g_prep.n_colours;
+    case 101: return g_prep.rowgather_ok ? 1 : 0;
+    case 102: return (int64_t)g_prep.rg_lds_bytes;
+  }
+  return -1;
+}
+int shim_prep_copy(int what, void* dst) {
+#define CP(v) std::memcpy(dst, g_prep.v.data(), g_prep.v.size() * sizeof(g_prep.v[0])); return 0
+  switch (what) {
+    case 0: CP(bptr);
+    case 1: CP(bcol);
+    case 2: CP(eslot);
+    case 3: CP(colour);
+    case 4: CP(elem_order);
+    case 5: CP(colour_ptr);
+    case 6: CP(first_mask);
+    case 7: CP(first_rhs);
+    case 8: CP(pair_elem);
+    case 9: CP(pair_local);
+    case 10: CP(node_pair_ptr);
+    case 11: CP(wg_node_ptr);
+  }
+#undef CP
+  return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Host mesh preparation (rdc_meshprep.cpp through the host shim): sparsity pattern, slot map,
+colouring, first-writer masks and row-gather work lists.  The scatter index arithmetic of both
+kernels is replayed here in numpy on top of the product's row function and compared with the
+oracle's MatSetValues-style assembly."""
+import numpy as np
+import pytest
+
+from conftest import shim_rows
+from rdcfes_amd import pihna_params_from_dict, hcc_params_from_dict, synth
+
+
+def _mesh(kind, n, order="random"):
+    return (synth.kuhn_tet_mesh(n, order=order) if kind == 4 else synth.hex_mesh(n, jitter=0.1, order=order))
+
+
+@pytest.mark.parametrize("nen,n", [(4, 3), (8, 3)])
+def test_pattern_equals_oracle(oracle, make_prep, nen, n):
+    conn, xyz = _mesh(nen, n)
+    P = make_prep(nen, conn, xyz.shape[0], xyz.shape[0], 3)
+    assert P.ok, P.error
+    _, _, bptr, bcol = oracle.build_pattern(nen, conn, xyz.shape[0], xyz.shape[0], 3)
+    np.testing.assert_array_equal(P.bptr, bptr)
+    np.testing.assert_array_equal(P.bcol, bcol)
+    # slot map points at the right column
+    es = P.eslot.reshape(-1, nen, nen)
+    for e in (0, conn.shape[0] // 2, conn.shape[0] - 1):
+        for i in range(nen):
+            for j in range(nen):
+                assert P.bcol[P.bptr[conn[e, i]] + es[e, i, j]] == conn[e, j]
+
+
+@pytest.mark.parametrize("nen,n", [(4, 4), (8, 4)])
+def test_colouring_is_valid(make_prep, nen, n):
+    conn, xyz = _mesh(nen, n)
+    P = make_prep(nen, conn, xyz.shape[0], xyz.shape[0], 1)
+    assert P.ok
+    assert P.colour.min() == 0 and P.colour.max() == P.n_colours - 1
+    for c in range(P.n_colours):
+        nodes = conn[P.colour == c].ravel()
+        assert np.unique(nodes).size == nodes.size, "two elements of one colour share a node"
+    # colour-sorted order and pointers are consistent
+    assert np.all(np.diff(P.colour[P.elem_order]) >= 0)
+    np.testing.assert_array_equal(np.bincount(P.colour, minlength=P.n_colours), np.diff(P.colour_ptr))
+    assert sorted(P.elem_order.tolist()) == list(range(conn.shape[0]))
+
+
+def _replay_coloured(P, conn, nen, nv, n_owned, rows_of):
+    nnz = nv * nv * P.bptr[n_owned]
+    val = np.full(nnz, np.nan)     # poisoned: the kernel must never rely on a memset
+    rhs = np.full(n_owned * nv, np.nan)
+    es = P.eslot.reshape(-1, nen, nen)
+    for e in P.elem_order:
+        Ke, Fe = rows_of(e)
+        fm, fr = int(P.first_mask[e]), int(P.first_rhs[e])
+        for i in range(nen):
+            I = conn[e, i]
+            if I >= n_owned:
+                continue
+            b0, ln = P.bptr[I], P.bptr[I + 1] - P.bptr[I]
+            for a in range(nv):
+                r = I * nv + a
+                rhs[r] = Fe[a * nen + i] if (fr >> i) & 1 else rhs[r] + Fe[a * nen + i]
+                for j in range(nen):
+                    pos = nv * nv * b0 + a * nv * ln + nv * es[e, i, j]
+                    blk = Ke[a * nen + i, j::nen][:nv]  # entries (a,i) x (b,j) for b = 0..nv-1
+                    if (fm >> (i * nen + j)) & 1:
+                        val[pos:pos + nv] = blk
+                    else:
+                        val[pos:pos + nv] += blk
+    return val, rhs
+
+
+def _replay_rowgather(P, conn, nen, nv, n_owned, rows_of):
+    nnz = nv * nv * P.bptr[n_owned]
+    val = np.full(nnz, np.nan)
+    rhs = np.full(n_owned * nv, np.nan)
+    es = P.eslot.reshape(-1, nen, nen)
+    cache = {}
+    for w in range(P.wg_node_ptr.size - 1):
+        n0, n1 = P.wg_node_ptr[w], P.wg_node_ptr[w + 1]
+        vb0 = nv * nv * P.bptr[n0]
+        lds = np.zeros(nv * nv * P.bptr[n1] - vb0)
+        lr = np.zeros((n1 - n0) * nv)
+        assert 8 * (lds.size + lr.size) <= P.rg_lds_bytes
+        for p in range(P.node_pair_ptr[n0], P.node_pair_ptr[n1]):
+            e, i = int(P.pair_elem[p]), int(P.pair_local[p])
+            if e not in cache:
+                cache[e] = rows_of(e)
+            Ke, Fe = cache[e]
+            I = conn[e, i]
+            assert n0 <= I < n1
+            ln = P.bptr[I + 1] - P.bptr[I]
+            base = nv * nv * P.bptr[I] - vb0
+            for a in range(nv):
+                lr[(I - n0) * nv + a] += Fe[a * nen + i]
+                for j in range(nen):
+                    pos = base + a * nv * ln + nv * es[e, i, j]
+                    lds[pos:pos + nv] += Ke[a * nen + i, j::nen][:nv]
+        val[vb0:vb0 + lds.size] = lds
+        rhs[n0 * nv:n1 * nv] = lr
+    return val, rhs
+
+
+@pytest.mark.parametrize("nen,model", [(4, 0), (8, 2)])
+@pytest.mark.parametrize("owned_frac", [1.0, 0.6])
+def test_scatter_replay_matches_oracle(oracle, shim, make_prep, nen, model, owned_frac):
+    conn, xyz = _mesh(nen, 3)
+    n_node = xyz.shape[0]
+    n_owned = int(round(owned_frac * n_node))
+    if n_owned < n_node:  # keep only elements touching an owned node (owned + ghost layer)
+        conn = conn[(conn < n_owned).any(axis=1)]
+    nv = 5 if model == 0 else 3
+    if model == 0:
+        p = pihna_params_from_dict(synth.pihna_param_dict("full"))
+        u = synth.pihna_fields(xyz)
+    else:
+        p = hcc_params_from_dict(synth.hcc_param_dict("full"))
+        u = synth.hcc_fields(xyz)
+    P = make_prep(nen, conn, n_node, n_owned, nv, lds_budget=24 * 1024)
+    assert P.ok, P.error
+    assert P.rowgather_ok
+    rows_of = lambda e: shim_rows(shim, model, nen, p, xyz[conn[e]], u[conn[e]], fast=(nen == 4))
+    row_ptr, col, val0, rhs0 = oracle.assemble(model, nen, conn, xyz, nv, p, u_old=u, n_owned=n_owned)
+    for replay in (_replay_coloured, _replay_rowgather):
+        val, rhs = replay(P, conn, nen, nv, n_owned, rows_of)
+        assert not np.isnan(val).any() and not np.isnan(rhs).any(), "some CSR entry was never written"
+        np.testing.assert_allclose(rhs, rhs0, rtol=1e-10, atol=1e-12 * np.abs(rhs0).max())
+        np.testing.assert_allclose(val, val0, rtol=1e-10, atol=1e-12 * np.abs(val0).max())
+
+
+def test_rowgather_workgroups_respect_limits(make_prep):
+    conn, xyz = synth.kuhn_tet_mesh(6, order="lex")
+    n = xyz.shape[0]
+    P = make_prep(4, conn, n, n, 5, lds_budget=60 * 1024, block=256)
+    assert P.rowgather_ok
+    wg = P.wg_node_ptr
+    assert wg[0] == 0 and wg[-1] == n and np.all(np.diff(wg) > 0)
+    pairs = P.node_pair_ptr[wg[1:]] - P.node_pair_ptr[wg[:-1]]
+    blocks = P.bptr[wg[1:]] - P.bptr[wg[:-1]]
+    bytes_ = 8 * (25 * blocks + 5 * np.diff(wg))
+    assert bytes_.max() == P.rg_lds_bytes <= 60 * 1024
+    single = np.diff(wg) == 1
+    assert np.all((pairs <= 256) | single)
+    assert P.node_pair_ptr[-1] == 4 * conn.shape[0]
+    # a budget smaller than one node row disables the strategy instead of overflowing LDS
+    P2 = make_prep(4, conn, n, n, 5, lds_budget=1024)
+    assert P2.ok and not P2.rowgather_ok
+
+
+def test_prep_rejects_bad_meshes(make_prep):
+    conn, xyz = synth.kuhn_tet_mesh(2)
+    n = xyz.shape[0]
+    bad = conn.copy(); bad[3, 1] = n
+    assert "out of range" in make_prep(4, bad, n, n, 1).error
+    bad = conn.copy(); bad[5, 2] = bad[5, 0]
+    assert "degenerate" in make_prep(4, bad, n, n, 1).error
+    assert "without any incident element" in make_prep(4, conn[:1], n, n, 1).error
+    assert "element type" in make_prep(5, conn, n, n, 1).error
+    assert "nvar" in make_prep(4, conn, n, n, 9).error
+    assert "bad mesh sizes" in make_prep(4, conn, n, n + 1, 1).error
+    # empty owned set is legal (a rank that owns nothing): nothing to assemble
+    P = make_prep(4, conn[:0], n, 0, 1)
+    assert P.ok and P.bptr.tolist() == [0]

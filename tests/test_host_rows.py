@@ -1,0 +1,110 @@
+"""The product's row evaluators (rdc_row.h generic, rdc_tet4_fast.h factored), compiled for the host
+by tests/host_shim.cpp, against the oracle's literal quadrature loops.  No GPU needed; the HIP
+kernels run the very same functions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import shim_rows
+from rdcfes_amd import hcc_params_from_dict, pihna_params_from_dict, ripf_params_from_dict, synth
+
+TET = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+HEX = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], float)
+
+
+def _case(model, nen, seed, variant):
+    rng = np.random.default_rng(seed)
+    X = (TET if nen == 4 else HEX) * rng.uniform(0.5, 2.0, 3) + 0.08 * rng.standard_normal((nen, 3))
+    aux = None
+    if model == 0:
+        p = pihna_params_from_dict(synth.pihna_param_dict(variant))
+        u = np.column_stack([rng.uniform(0, 500, nen), rng.uniform(0, 2e3, nen), rng.uniform(0, 2e3, nen),
+                             rng.uniform(3e3, 7e3, nen), rng.uniform(0, 1e-8, nen)])
+    elif model == 1:
+        p = ripf_params_from_dict(synth.ripf_param_dict(variant))
+        u = np.column_stack([rng.uniform(-1000, 1000, nen), rng.uniform(0, 1, nen) * (rng.random(nen) < 0.7),
+                             rng.uniform(0, 0.3, nen)])
+        aux = np.column_stack([rng.uniform(-1e-2, 1e-2, nen), rng.uniform(-1e-2, 1e-2, nen), rng.uniform(0, 70, nen)])
+    else:
+        p = hcc_params_from_dict(synth.hcc_param_dict(variant))
+        u = rng.uniform(0, 0.3, (nen, 3))
+    return X, u, aux, p
+
+
+CASES = [(0, "shipped"), (0, "full"), (0, "realexp"), (1, "shipped"), (1, "full"), (2, "full"), (2, "shipped")]
+
+
+@pytest.mark.parametrize("model,variant", CASES)
+@pytest.mark.parametrize("nen", [4, 8])
+def test_generic_row_matches_oracle(oracle, shim, model, variant, nen):
+    for seed in range(3):
+        X, u, aux, p = _case(model, nen, seed, variant)
+        Ke0, Fe0 = oracle.element(model, nen, X, u, p, aux=aux)
+        Ke1, Fe1 = shim_rows(shim, model, nen, p, X, u, aux)
+        s = np.abs(Ke0).max()
+        np.testing.assert_allclose(Ke1, Ke0, rtol=1e-11, atol=1e-13 * s)
+        np.testing.assert_allclose(Fe1, Fe0, rtol=1e-11, atol=1e-13 * np.abs(Fe0).max())
+
+
+@pytest.mark.parametrize("model,variant", CASES)
+def test_tet4_factored_row_matches_oracle(oracle, shim, model, variant):
+    for seed in range(5):
+        X, u, aux, p = _case(model, 4, 100 + seed, variant)
+        Ke0, Fe0 = oracle.element(model, 4, X, u, p, aux=aux)
+        Ke1, Fe1 = shim_rows(shim, model, 4, p, X, u, aux, fast=True)
+        s = np.abs(Ke0).max()
+        np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-12 * s)
+        np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-12 * np.abs(Fe0).max())
+
+
+def test_integer_exponent_shortcut_equals_pow(shim):
+    """EXP_MODE 3 (x*x*x) against the general pow() instantiation of the same code."""
+    X, u, aux, p = _case(0, 4, 7, "full")
+    a = shim_rows(shim, 0, 4, p, X, u, fast=True)
+    b = shim_rows(shim, 0, 4, p, X, u, fast=True, force_general_pow=True)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-13, atol=1e-15 * np.abs(b[0]).max())
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-13)
+
+
+@pytest.mark.parametrize("model,variant", CASES)
+def test_structural_masks_cover_all_nonzeros(shim, model, variant):
+    rng = np.random.default_rng(11)
+    _, u, aux, p = _case(model, 4, 3, variant)
+    w = C.c_double(-1.0)
+    for n in range(4):
+        a = None if aux is None else np.ascontiguousarray(aux[n])
+        un = np.ascontiguousarray(u[n])
+        rc = shim.shim_masks(model, C.byref(p), un.ctypes.data_as(C.POINTER(C.c_double)),
+                             None if a is None else a.ctypes.data_as(C.POINTER(C.c_double)), C.byref(w))
+        assert rc == 0 and w.value == 0.0
+
+
+def test_pihna_nan_path_matches_reference_semantics(oracle, shim):
+    """c+h+v == 0 at a quadrature point: Ve_ = 0/0 = NaN falls through both comparisons
+    (src/pihna.C:477-498, App. D.5); both implementations must propagate the same NaN pattern."""
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    u = np.zeros((4, 5))
+    u[:, 0] = 1.0
+    Ke0, Fe0 = oracle.element(0, 4, TET, u, p)
+    for fast in (False, True):
+        Ke1, Fe1 = shim_rows(shim, 0, 4, p, TET, u, fast=fast)
+        np.testing.assert_array_equal(np.isnan(Ke1), np.isnan(Ke0))
+        np.testing.assert_array_equal(np.isnan(Fe1), np.isnan(Fe0))
+        assert np.isnan(Fe0).any()
+
+
+def test_threshold_branches(oracle, shim):
+    """crowding saturation (Te >= 1 -> Tau = 0), Te <= 0 and the cells_min_capacity switches."""
+    d = synth.pihna_param_dict("full")
+    p = pihna_params_from_dict(d)
+    rng = np.random.default_rng(12)
+    X = TET + 0.05 * rng.standard_normal((4, 3))
+    for u in (np.tile([1e5, 1e5, 1e5, 1e5, 1e-9], (4, 1)),        # Te > 1
+              np.tile([0.0, 0.5, 0.5, 0.9, 0.0], (4, 1)),          # below cells_min_capacity
+              np.column_stack([rng.uniform(0, 2, 4)] * 4 + [rng.uniform(0, 1e-8, 4)])):  # straddles Lambda_k = 1
+        Ke0, Fe0 = oracle.element(0, 4, X, u, p)
+        for fast in (False, True):
+            Ke1, Fe1 = shim_rows(shim, 0, 4, p, X, u, fast=fast)
+            np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-12 * np.abs(Ke0).max())
+            np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-12 * max(np.abs(Fe0).max(), 1e-300))
