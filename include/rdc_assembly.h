@@ -196,10 +196,14 @@ int rdc_csr_download(rdc_ctx* ctx, double* val, double* rhs);
 int rdc_clamp_nonnegative(rdc_ctx* ctx, int field);
 
 /* ---- instrumentation ---- */
-/* when enabled every rdc_assemble_* brackets its kernels with HIP events on the context stream */
+/* when enabled every rdc_assemble_* brackets its dominant kernel(s) -- the assembly kernel, or all
+ * colour launches; not the small node-record pack -- with HIP events on the context stream */
 int rdc_timing_enable(rdc_ctx* ctx, int on);
 /* device time of the last assemble call in ms (valid after the stream has been synchronised) */
 int rdc_timing_last_ms(rdc_ctx* ctx, float* ms);
+/* sum of the device times of every assemble call since the last enable / sum, and their count;
+ * synchronises on the recorded events and resets the pool (no host sync happens inside assemble) */
+int rdc_timing_sum_ms(rdc_ctx* ctx, float* total_ms, int* n_calls);
 
 #ifdef __cplusplus
 }

@@ -190,3 +190,9 @@ class AssemblyContext:
         ms = C.c_float()
         self._ck(self._lib.rdc_timing_last_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def timing_sum_ms(self):
+        """(total device ms, number of assemble calls) since the last enable / sum; resets the pool."""
+        ms, n = C.c_float(), C.c_int()
+        self._ck(self._lib.rdc_timing_sum_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -43,8 +43,8 @@ struct rdc_ctx {
   int64_t n_sides = 0;
   // timing
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool ev_valid = false;
+  std::vector<hipEvent_t> ev;   // pairs (start, stop), one pair per timed assemble call
+  size_t ev_used = 0;           // events handed out since the last rdc_timing_sum_ms / enable
   size_t max_lds = 64 * 1024;
 };
 
@@ -143,6 +143,21 @@ int resolve_strategy(rdc_ctx* c, int* out) {
   return RDC_OK;
 }
 
+// hands out the next (start, stop) event pair of the timing pool, growing it on demand
+int next_event_pair(rdc_ctx* c, hipEvent_t* start, hipEvent_t* stop) {
+  if (c->ev_used + 2 > c->ev.size()) {
+    for (int x = 0; x < 2; x++) {
+      hipEvent_t e = nullptr;
+      RDC_HIP(c, hipEventCreate(&e));
+      c->ev.push_back(e);
+    }
+  }
+  *start = c->ev[c->ev_used];
+  *stop = c->ev[c->ev_used + 1];
+  c->ev_used += 2;
+  return RDC_OK;
+}
+
 template <class M, class P>
 int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (!c) return RDC_ERR_INVALID;
@@ -172,13 +187,14 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.n_colours = c->prep.n_colours;
   a.n_wg = c->prep.rowgather_ok ? (int)c->prep.wg_node_ptr.size() - 1 : 0;
   a.lds_bytes = c->prep.rg_lds_bytes;
-  if (c->timing) RDC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  a.ev_start = nullptr;
+  hipEvent_t ev_stop = nullptr;
+  if (c->timing) {
+    if ((rc = next_event_pair(c, &a.ev_start, &ev_stop))) return rc;
+  }
   hipError_t e = launch_rd<M>(a, k);
   if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-  if (c->timing) {
-    RDC_HIP(c, hipEventRecord(c->ev1, c->stream));
-    c->ev_valid = true;
-  }
+  if (c->timing) RDC_HIP(c, hipEventRecord(ev_stop, c->stream));
   return RDC_OK;
 }
 
@@ -204,8 +220,6 @@ int rdc_ctx_create(int device_ordinal, rdc_ctx** out) {
   if (!c) return fail(nullptr, RDC_ERR_ALLOC, "out of host memory");
   c->device = device_ordinal;
   e = hipSetDevice(device_ordinal);
-  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
   if (e != hipSuccess) {
     delete c;
     return fail(nullptr, RDC_ERR_HIP, "device initialisation failed: %s", hipGetErrorString(e));
@@ -226,8 +240,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
   return RDC_OK;
 }
@@ -277,7 +290,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   if (rc) return rc;
   c->have_mesh = false;
   // LDS budget of a row-gather workgroup: half the per-block limit keeps two workgroups per CU
-  const size_t budget = c->max_lds >= 64 * 1024 ? 60 * 1024 : c->max_lds / 2;
+  const size_t budget = c->max_lds >= 64 * 1024 ? 36 * 1024 : c->max_lds / 2;
   std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, 256, c->prep);
   if (!err.empty()) return fail(c, RDC_ERR_INVALID, "%s", err.c_str());
   const HostPrep& P = c->prep;
@@ -503,13 +516,14 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   a.stream = c->stream;
   a.colour_ptr = c->prep.colour_ptr.data();
   a.n_colours = c->prep.n_colours;
-  if (c->timing) RDC_HIP(c, hipEventRecord(c->ev0, c->stream));
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  if (c->timing) {
+    if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
+    RDC_HIP(c, hipEventRecord(ev_start, c->stream));
+  }
   hipError_t e = launch_solid(a);
   if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "solid kernel launch failed: %s", hipGetErrorString(e));
-  if (c->timing) {
-    RDC_HIP(c, hipEventRecord(c->ev1, c->stream));
-    c->ev_valid = true;
-  }
+  if (c->timing) RDC_HIP(c, hipEventRecord(ev_stop, c->stream));
   return RDC_OK;
 }
 
@@ -551,17 +565,34 @@ int rdc_clamp_nonnegative(rdc_ctx* c, int field) {
 int rdc_timing_enable(rdc_ctx* c, int on) {
   if (!c) return RDC_ERR_INVALID;
   c->timing = on != 0;
-  c->ev_valid = false;
+  c->ev_used = 0;
   return RDC_OK;
 }
 
 int rdc_timing_last_ms(rdc_ctx* c, float* ms) {
   if (!c || !ms) return RDC_ERR_INVALID;
-  if (!c->ev_valid) return fail(c, RDC_ERR_STATE, "no timed assemble call recorded");
+  if (c->ev_used < 2) return fail(c, RDC_ERR_STATE, "no timed assemble call recorded");
   int rc = set_device(c);
   if (rc) return rc;
-  RDC_HIP(c, hipEventSynchronize(c->ev1));
-  RDC_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  RDC_HIP(c, hipEventSynchronize(c->ev[c->ev_used - 1]));
+  RDC_HIP(c, hipEventElapsedTime(ms, c->ev[c->ev_used - 2], c->ev[c->ev_used - 1]));
+  return RDC_OK;
+}
+
+int rdc_timing_sum_ms(rdc_ctx* c, float* total_ms, int* n_calls) {
+  if (!c || !total_ms || !n_calls) return RDC_ERR_INVALID;
+  int rc = set_device(c);
+  if (rc) return rc;
+  float total = 0.0f;
+  for (size_t x = 0; x + 1 < c->ev_used; x += 2) {
+    float ms = 0.0f;
+    RDC_HIP(c, hipEventSynchronize(c->ev[x + 1]));
+    RDC_HIP(c, hipEventElapsedTime(&ms, c->ev[x], c->ev[x + 1]));
+    total += ms;
+  }
+  *total_ms = total;
+  *n_calls = (int)(c->ev_used / 2);
+  c->ev_used = 0;
   return RDC_OK;
 }
 

@@ -24,6 +24,7 @@ struct LaunchArgs {
   double* val;
   double* rhs;
   hipStream_t stream;
+  hipEvent_t ev_start;  // recorded right before the dominant kernel(s) when timing is on, else null
   const int64_t* colour_ptr;  // host
   int n_colours;
   int n_wg;

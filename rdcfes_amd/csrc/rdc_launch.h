@@ -8,6 +8,7 @@ namespace rdc {
 
 template <class M, int NEN, int EXP_MODE>
 static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
+  if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
   if (a.strategy == RDC_SCATTER_ROWGATHER) {
     constexpr int BLOCK = 256;
     if (a.n_wg > 0)

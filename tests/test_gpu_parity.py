@@ -1,0 +1,251 @@
+"""GPU parity: HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+Tolerance: north_star asks for the global residual L2 within 1e-10 relative; the same bound is
+applied to the matrix (Frobenius) and to A*x for a seeded random x."""
+import numpy as np
+import pytest
+
+from rdcfes_amd import (AssemblyContext, RdcError, SolidMaterial, SolidParams, hcc_params_from_dict,
+                        pihna_params_from_dict, ripf_params_from_dict, synth)
+from rdcfes_amd.context import (FIELD_AUX_NODAL, FIELD_ELEM_FIBRE, FIELD_OLD_SOLUTION, FIELD_UNDEFORMED_XYZ,
+                                SCATTER_COLOURED, SCATTER_ROWGATHER, VARIANT_AUTO, VARIANT_GENERIC)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def csr_matvec(row_ptr, col, val, x):
+    y = np.add.reduceat(val * x[col], row_ptr[:-1])
+    return y
+
+
+def _inputs(model, nen, n, order="random", variant="full"):
+    conn, xyz = synth.kuhn_tet_mesh(n, order=order) if nen == 4 else synth.hex_mesh(n, jitter=0.15, order=order)
+    aux = None
+    if model == 0:
+        p, u = pihna_params_from_dict(synth.pihna_param_dict(variant)), synth.pihna_fields(xyz)
+    elif model == 1:
+        p = ripf_params_from_dict(synth.ripf_param_dict(variant))
+        u, aux = synth.ripf_fields(xyz)
+    else:
+        p, u = hcc_params_from_dict(synth.hcc_param_dict(variant)), synth.hcc_fields(xyz)
+    return conn, xyz, u, aux, p
+
+
+def _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, n_owned=None):
+    nv = 5 if model == 0 else 3
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(nen, conn, xyz, nv, n_owned=n_owned)
+        ctx.set_scatter(strategy)
+        ctx.set_kernel_variant(variant)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        if aux is not None:
+            ctx.field_upload(FIELD_AUX_NODAL, aux)
+        [ctx.assemble_pihna, ctx.assemble_ripf, ctx.assemble_hcc][model](p)
+        val, rhs = ctx.csr_download()
+        row_ptr, col = ctx.csr_pattern()
+        # a second call must give the same answer (no state carried in val/rhs between steps)
+        [ctx.assemble_pihna, ctx.assemble_ripf, ctx.assemble_hcc][model](p)
+        val2, rhs2 = ctx.csr_download()
+    assert rel(val2, val) < 1e-13 and rel(rhs2, rhs) < 1e-13
+    return row_ptr, col, val, rhs
+
+
+COMBOS = [(m, nen, s, v, pv)
+          for m, pvs in ((0, ("full", "shipped", "realexp")), (1, ("full", "shipped")), (2, ("full",)))
+          for pv in pvs
+          for nen in (4, 8)
+          for s in (SCATTER_COLOURED, SCATTER_ROWGATHER)
+          for v in ((VARIANT_AUTO, VARIANT_GENERIC) if nen == 4 else (VARIANT_GENERIC,))
+          if not (m == 0 and nen == 8 and pv != "full")]
+
+
+@pytest.mark.parametrize("model,nen,strategy,variant,pvariant", COMBOS)
+def test_parity_small_mesh(oracle, model, nen, strategy, variant, pvariant):
+    conn, xyz, u, aux, p = _inputs(model, nen, 6 if nen == 4 else 7, variant=pvariant)
+    nv = 5 if model == 0 else 3
+    rp0, col0, val0, rhs0 = oracle.assemble(model, nen, conn, xyz, nv, p, u_old=u, aux=aux)
+    rp, col, val, rhs = _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant)
+    np.testing.assert_array_equal(rp, rp0)
+    np.testing.assert_array_equal(col, col0)
+    assert rel(rhs, rhs0) < TOL
+    assert rel(val, val0) < TOL
+    x = np.random.default_rng(1).standard_normal(xyz.shape[0] * nv)
+    assert rel(csr_matvec(rp, col, val, x), csr_matvec(rp0, col0, val0, x)) < TOL
+
+
+@pytest.mark.parametrize("strategy", [SCATTER_COLOURED, SCATTER_ROWGATHER])
+def test_parity_ghosted_partition(oracle, strategy):
+    """rows only for owned nodes; ghost nodes contribute columns."""
+    conn, xyz, u, aux, p = _inputs(0, 4, 6)
+    n_node = xyz.shape[0]
+    n_owned = int(0.55 * n_node)
+    conn = conn[(conn < n_owned).any(axis=1)]
+    rp0, col0, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u, n_owned=n_owned)
+    rp, col, val, rhs = _gpu_assemble(0, 4, conn, xyz, u, None, p, strategy, VARIANT_AUTO, n_owned=n_owned)
+    assert rhs.size == n_owned * 5
+    np.testing.assert_array_equal(rp, rp0)
+    np.testing.assert_array_equal(col, col0)
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
+def test_parity_cfg2_full_size(oracle):
+    """BASELINE configs[1]: PIHNA, K(55) = 998,250 TET4 / 175,616 nodes, shipped parameters."""
+    conn, xyz, u, aux, p = _inputs(0, 4, 55, order="lex", variant="shipped")
+    assert conn.shape[0] == 998250 and xyz.shape[0] == 175616
+    rp0, col0, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    rp, col, val, rhs = _gpu_assemble(0, 4, conn, xyz, u, None, p, SCATTER_ROWGATHER, VARIANT_AUTO)
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+    rp, col, val, rhs = _gpu_assemble(0, 4, conn, xyz, u, None, p, SCATTER_COLOURED, VARIANT_AUTO)
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
+def test_full_size_properties_10m_tets():
+    """K(119), 10.1M tets (the metric's mesh): size-independent checks instead of the oracle.
+    (1) zero-rate parameters: every diagonal block is the mass matrix -> its entries sum to the
+        volume (1), rhs sums to the integral of u_old; off-diagonal blocks vanish;
+    (2) the two independent scatter paths (coloured RMW vs row gather) agree."""
+    import torch
+    conn, xyz = synth.kuhn_tet_mesh(119, order="lex")
+    assert conn.shape[0] == 10110954
+    u = synth.pihna_fields(xyz)
+    p0 = pihna_params_from_dict({"time_step": 0.1, "cells_max_capacity": 2.39e5, "cells_max_capacity/exponent": 3.0,
+                                 "cytokines_max_capacity": 1e-8})
+    p1 = pihna_params_from_dict(synth.pihna_param_dict("full"))
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        n_rows, nnz = ctx.csr_dims()
+        ctx.set_scatter(SCATTER_ROWGATHER)
+        ctx.assemble_pihna(p0)
+        val, rhs = ctx.csr_download()
+        row_ptr, col = ctx.csr_pattern()
+        a_of_row = np.arange(n_rows) % 5
+        b_of_col = col % 5
+        row_of = np.repeat(np.arange(n_rows), np.diff(row_ptr))
+        diag = a_of_row[row_of] == b_of_col
+        assert np.abs(val[~diag]).max() == 0.0
+        for a in range(5):
+            s = val[diag & (a_of_row[row_of] == a)].sum()
+            assert abs(s - 1.0) < 1e-9
+        X = xyz[conn]
+        vol = np.abs(np.einsum("ei,ei->e", X[:, 1] - X[:, 0], np.cross(X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]))) / 6
+        for a in range(5):
+            integral = (vol * u[conn][:, :, a].mean(axis=1)).sum()
+            assert abs(rhs[a::5].sum() - integral) <= 1e-9 * max(abs(integral), 1e-300)
+        del val, rhs, row_of, diag, b_of_col, col
+        ctx.assemble_pihna(p1)
+        v_rg, r_rg = ctx.csr_download()
+        ctx.set_scatter(SCATTER_COLOURED)
+        ctx.assemble_pihna(p1)
+        v_c, r_c = ctx.csr_download()
+    assert rel(v_c, v_rg) < 1e-12 and rel(r_c, r_rg) < 1e-12
+
+
+def test_moving_mesh_hcc(oracle):
+    """assemble_hcc runs on the CURRENT (deformed) coordinates (src/coupled_hcc.C:98-114)."""
+    conn, xyz, u, aux, p = _inputs(2, 8, 6, order="lex")
+    xyz2 = xyz + synth.solid_displacement(xyz)
+    _, _, val0, rhs0 = oracle.assemble(2, 8, conn, xyz2, 3, p, u_old=u)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(8, conn, xyz, 3)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_hcc(p)
+        v_undeformed, _ = ctx.csr_download()
+        ctx.mesh_update_coords(xyz2)
+        ctx.assemble_hcc(p)
+        val, rhs = ctx.csr_download()
+    assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
+    assert rel(v_undeformed, val0) > 1e-4
+
+
+def _solid_case(nen, n, seed=0):
+    rng = np.random.default_rng(seed)
+    conn, Xu = synth.kuhn_tet_mesh(n, jitter=0.1, order="random") if nen == 4 else synth.hex_mesh(n, jitter=0.1, order="random")
+    x = Xu + synth.solid_displacement(Xu, amp=0.02)
+    ne = conn.shape[0]
+    cen = Xu[conn].mean(axis=1)
+    em = (np.linalg.norm(cen - 0.5, axis=1) < 0.3).astype(np.int32)
+    mats = [SolidMaterial(2.0e3, 0.4, 0.0, (0.0, 0.0, 0.0)), SolidMaterial(1.5e3, 0.35, 40.0, (0.3, 0.2, 0.1))]
+    fibre = rng.standard_normal((ne, 3))
+    se0, ss0 = synth.boundary_sides(nen, conn, Xu, 2, 0.0)
+    se1, ss1 = synth.boundary_sides(nen, conn, Xu, 2, 1.0)
+    se = np.concatenate([se0, se1])
+    ss = np.concatenate([ss0, ss1])
+    sd = np.concatenate([np.zeros((se0.size, 3)), np.tile([np.nan, np.nan, -0.75], (se1.size, 1))])
+    return conn, Xu, x, em, mats, fibre, (se, ss, sd)
+
+
+@pytest.mark.parametrize("nen,n", [(8, 5), (4, 4)])
+@pytest.mark.parametrize("use_symmetry", [0, 1])
+@pytest.mark.parametrize("jac", [True, False])
+def test_solid_parity(oracle, nen, n, use_symmetry, jac):
+    conn, Xu, x, em, mats, fibre, sides = _solid_case(nen, n)
+    sp = SolidParams(0.4, 1.0e5, use_symmetry, 0)
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_SOLID, nen, conn, x, 3, sp, xyz_undeformed=Xu, elem_fibre=fibre,
+                                       elem_material=em, materials=mats, request_jacobian=jac, sides=sides)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(nen, conn, x, 3)
+        ctx.field_upload(FIELD_UNDEFORMED_XYZ, Xu)
+        ctx.field_upload(FIELD_ELEM_FIBRE, fibre)
+        ctx.solid_set_materials(em, mats)
+        ctx.solid_set_sides(*sides)
+        ctx.solid_assemble(sp, jac)
+        val, rhs = ctx.csr_download()
+    assert rel(rhs, rhs0) < TOL
+    if jac:
+        assert rel(val, val0) < TOL
+    else:
+        assert np.all(val == 0.0)
+
+
+def test_clamp_nonnegative(oracle):
+    conn, xyz = synth.kuhn_tet_mesh(3)
+    u = np.random.default_rng(3).standard_normal((xyz.shape[0], 5))
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.clamp_nonnegative(FIELD_OLD_SOLUTION)
+        out = ctx.field_download(FIELD_OLD_SOLUTION, u.size)
+    np.testing.assert_array_equal(out, oracle.clamp_nonnegative(u).ravel())
+
+
+def test_error_behaviour():
+    """int status codes instead of libmesh_error() aborts."""
+    conn, xyz = synth.kuhn_tet_mesh(2)
+    p = pihna_params_from_dict(synth.pihna_param_dict())
+    with AssemblyContext(0) as ctx:
+        with pytest.raises(RdcError) as e:
+            ctx.assemble_pihna(p)
+        assert e.value.code == 3  # RDC_ERR_STATE: no mesh
+        ctx.mesh_upload(4, conn, xyz, 5)
+        with pytest.raises(RdcError) as e:
+            ctx.assemble_pihna(p)
+        assert e.value.code == 3  # old solution missing
+        with pytest.raises(RdcError) as e:
+            ctx.field_upload(FIELD_OLD_SOLUTION, np.zeros(7))
+        assert e.value.code == 1
+        with pytest.raises(RdcError) as e:
+            ctx.assemble_hcc(hcc_params_from_dict(synth.hcc_param_dict()))
+        assert e.value.code == 1  # nvar mismatch
+        bad = conn.copy()
+        bad[0, 0] = 10 ** 6
+        with pytest.raises(RdcError) as e:
+            ctx.mesh_upload(4, bad, xyz, 5)
+        assert e.value.code == 1 and "out of range" in str(e.value)
+    with pytest.raises(RdcError):
+        AssemblyContext(10 ** 4)
+
+
+def test_timing_hook():
+    conn, xyz, u, aux, p = _inputs(0, 4, 8)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.timing_enable(True)
+        ctx.assemble_pihna(p)
+        ctx.synchronize()
+        assert 0.0 < ctx.timing_last_ms() < 1e4
