@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--scatter", default="auto", choices=["auto", "coloured", "rowgather"])
     ap.add_argument("--variant", default="auto", choices=["auto", "generic"])
     ap.add_argument("--order", default="lex", choices=["lex", "random"])
+    ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (rdc_set_option)")
     ap.add_argument("--cpu-sample", type=int, default=60, help="K(m) sample for the CPU baseline (0 = skip)")
     a = ap.parse_args()
 
@@ -101,6 +102,9 @@ def main():
     ctx.mesh_upload(4, l_conn, l_xyz, 5, n_owned=n_owned)
     ctx.set_scatter({"auto": 0, "coloured": 1, "rowgather": 2}[a.scatter])
     ctx.set_kernel_variant({"auto": 0, "generic": 1}[a.variant])
+    for kv in a.opt:
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     u_t = torch.from_numpy(np.ascontiguousarray(l_u)).to(dev)
     ctx.field_bind_device(FIELD_OLD_SOLUTION, u_t.data_ptr(), u_t.numel())
     hx = HaloExchange(lp, 5, dev) if world > 1 else None
@@ -152,7 +156,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"PIHNA TET4 K({a.n}): {n_elem_global} tets, {n_node_global} nodes, 5 unknowns, "
                                    f"params run/PIHNA/input.dat ({a.params}), order={a.order}",
-                       "scatter": ["auto", "coloured", "rowgather"][ctx.get_scatter()], "kernel_variant": a.variant,
+                       "scatter": ["auto", "coloured", "rowgather"][ctx.get_scatter()], "kernel_variant": a.variant, "options": a.opt,
                        "parallelism": f"element partition x{world}, 1 ghost layer, halo p2p over RCCL" if world > 1 else "single GPU",
                        "rank0_local_elements": int(l_conn.shape[0]), "rank0_nnz": int(nnz)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

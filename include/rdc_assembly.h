@@ -145,6 +145,9 @@ int rdc_synchronize(rdc_ctx* ctx);
 int rdc_set_scatter(rdc_ctx* ctx, int strategy);
 int rdc_get_scatter(const rdc_ctx* ctx, int* strategy);
 int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
+/* tuning / profiling knobs, not needed for normal use.  "occupancy": launch-bound waves per SIMD of
+ * the TET4 row-gather kernel; "ablate": 1/2 remove parts of that kernel (results are then WRONG) */
+int rdc_set_option(rdc_ctx* ctx, const char* key, int value);
 
 /* ---- mesh / pattern (one-time set-up; replaces es.init()) ---- */
 /* conn: [n_elem][elem_type] local node ids, libMesh/Gmsh node order; xyz: [n_node][3]. */

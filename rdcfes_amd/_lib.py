@@ -25,6 +25,7 @@ SIGNATURES = {
     "rdc_set_scatter": (C.c_int, [ctx_p, C.c_int]),
     "rdc_get_scatter": (C.c_int, [ctx_p, P(C.c_int)]),
     "rdc_set_kernel_variant": (C.c_int, [ctx_p, C.c_int]),
+    "rdc_set_option": (C.c_int, [ctx_p, C.c_char_p, C.c_int]),
     "rdc_mesh_upload": (C.c_int, [ctx_p, C.c_int, i64, i64, i64, P(u32), P(dbl), C.c_int]),
     "rdc_mesh_update_coords": (C.c_int, [ctx_p, P(dbl)]),
     "rdc_mesh_coords_device_ptr": (C.c_int, [ctx_p, P(C.c_void_p)]),

@@ -71,6 +71,9 @@ class AssemblyContext:
     def set_kernel_variant(self, variant):
         self._ck(self._lib.rdc_set_kernel_variant(self._h, int(variant)))
 
+    def set_option(self, key, value):
+        self._ck(self._lib.rdc_set_option(self._h, key.encode(), int(value)))
+
     def get_scatter(self):
         s = C.c_int()
         self._ck(self._lib.rdc_get_scatter(self._h, C.byref(s)))

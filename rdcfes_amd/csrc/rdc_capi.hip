@@ -30,6 +30,7 @@ struct rdc_ctx {
   bool have_mesh = false;
   int strategy = RDC_SCATTER_AUTO;
   int variant = RDC_VARIANT_AUTO;
+  int opt_occ = 2, opt_ablate = 0;
   HostPrep prep;
   // device mesh data
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
@@ -180,6 +181,8 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.aux = (const double*)c->field[RDC_FIELD_AUX_NODAL].p;
   a.packed = (double*)c->packed.p;
   a.variant = c->variant;
+  a.opt_occ = c->opt_occ;
+  a.opt_ablate = c->opt_ablate;
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
   a.stream = c->stream;
@@ -271,6 +274,14 @@ int rdc_set_kernel_variant(rdc_ctx* c, int v) {
   if (!c) return RDC_ERR_INVALID;
   if (v != RDC_VARIANT_AUTO && v != RDC_VARIANT_GENERIC) return fail(c, RDC_ERR_INVALID, "unknown kernel variant %d", v);
   c->variant = v;
+  return RDC_OK;
+}
+
+int rdc_set_option(rdc_ctx* c, const char* key, int value) {
+  if (!c || !key) return RDC_ERR_INVALID;
+  if (!std::strcmp(key, "occupancy")) c->opt_occ = value;
+  else if (!std::strcmp(key, "ablate")) c->opt_ablate = value;
+  else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
 }
 

@@ -64,11 +64,29 @@ RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
   else { p = pow(x, e); pm1 = pow(x, e - 1.0); }
 }
 
+// 1/x.  The reference divides (IEEE); on the device a correctly rounded FP64 division costs ~11
+// instructions, so quotients sharing a denominator use one reciprocal: v_rcp_f64 (~1e-8 rel) plus
+// two Newton steps (<= 1 ulp off the IEEE quotient, far inside the 1e-10 parity bound).
+// 0 -> inf/NaN propagate as in the quotient they replace.
+RDC_HD double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 // =========================================================================================
 // PIHNA: unknowns (n, c, h, v, a); gradient fields k = 0..3 -> (c, h, v, a)
 // =========================================================================================
 struct PihnaK {  // src/pihna.C:358-381
   double DT2, Lambda, Kappa, Ka, ek;
+  double iKappa, mekK;  // 1/Kappa, -ek/Kappa
   double nec_c, nec_h, nec_v;
   double dif_c, tax_c, dif_h, tax_h, prod_c, c2h, h2c, h2n;
   double dif_v, tax_v, prod_v;
@@ -102,6 +120,8 @@ struct Pihna {
     k.Kappa = p.cells_max_capacity;
     k.Ka = p.cytokines_max_capacity;
     k.ek = p.cells_max_capacity_exponent;
+    k.iKappa = 1.0 / k.Kappa;
+    k.mekK = -k.ek / k.Kappa;          // (-ek/Kappa_k), :470
     k.nec_c = p.necrosis_c / k.Kappa;  // :364-366
     k.nec_h = p.necrosis_h / k.Kappa;
     k.nec_v = p.necrosis_v / k.Kappa;
@@ -125,23 +145,24 @@ struct Pihna {
   template <int EXP_MODE>
   RDC_HD static void point(const K& k, const double* u, const double* /*aux*/, Pt& s) {
     s.n = u[0]; s.c = u[1]; s.h = u[2]; s.v = u[3]; s.a = u[4];
-    const double Te = (s.n + s.c + s.h + s.v) / k.Kappa;
+    const double Te = (s.n + s.c + s.h + s.v) * k.iKappa;
     if (Te <= 0.0) { s.Tau = 1.0; s.dT = 0.0; }
     else if (Te >= 1.0) { s.Tau = 0.0; s.dT = 0.0; }
     else {
       double p, pm1;
       pow_pair<EXP_MODE>(1.0 - Te, k.ek, p, pm1);
       s.Tau = p;
-      s.dT = (-k.ek / k.Kappa) * pm1;
+      s.dT = k.mekK * pm1;
     }
     const double chv = s.c + s.h + s.v;
-    const double Ve_ = s.v / chv;  // NaN for chv == 0 drops into the last branch, as upstream
+    const double rchv = rcp(chv);
+    const double Ve_ = s.v * rchv;  // NaN for chv == 0 drops into the last branch, as upstream
     if (Ve_ <= 0.0) { s.Ve = 0.0; s.Ve_dc = 0.0; s.Ve_dv = 0.0; }
     else if (Ve_ >= 1.0) { s.Ve = 1.0; s.Ve_dc = 0.0; s.Ve_dv = 0.0; }
-    else { s.Ve = Ve_; s.Ve_dc = -Ve_ / chv; s.Ve_dv = (1.0 - Ve_) / chv; }
-    const double aK = s.a + k.Ka;
-    s.Ua = s.a / aK;
-    s.Ua_da = 1.0 / aK - s.Ua / aK;
+    else { s.Ve = Ve_; s.Ve_dc = -Ve_ * rchv; s.Ve_dv = (1.0 - Ve_) * rchv; }
+    const double raK = rcp(s.a + k.Ka);
+    s.Ua = s.a * raK;
+    s.Ua_da = raK - s.Ua * raK;
     s.dif_c = (s.c > k.Lambda ? k.dif_c : 0.0); s.tax_c = (s.c > k.Lambda ? k.tax_c : 0.0);
     s.dif_h = (s.h > k.Lambda ? k.dif_h : 0.0); s.tax_h = (s.h > k.Lambda ? k.tax_h : 0.0);
     s.dif_v = (s.v > k.Lambda ? k.dif_v : 0.0); s.tax_v = (s.v > k.Lambda ? k.tax_v : 0.0);

@@ -21,6 +21,7 @@ struct LaunchArgs {
   const double* aux;
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
+  int opt_occ, opt_ablate;  // tuning knobs (rdc_set_option)
   double* val;
   double* rhs;
   hipStream_t stream;

@@ -37,7 +37,7 @@ RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const dou
   G[2][0] = e3[1] * e1[2] - e3[2] * e1[1]; G[2][1] = e3[2] * e1[0] - e3[0] * e1[2]; G[2][2] = e3[0] * e1[1] - e3[1] * e1[0];
   G[3][0] = e1[1] * e2[2] - e1[2] * e2[1]; G[3][1] = e1[2] * e2[0] - e1[0] * e2[2]; G[3][2] = e1[0] * e2[1] - e1[1] * e2[0];
   const double det = e1[0] * G[1][0] + e1[1] * G[1][1] + e1[2] * G[1][2];
-  const double inv = 1.0 / det;
+  const double inv = rcp(det);
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     G[1][d] *= inv; G[2][d] *= inv; G[3][d] *= inv;
