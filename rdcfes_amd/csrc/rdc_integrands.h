@@ -139,7 +139,6 @@ struct Pihna {
     double Tau, dT;            // crowding and its (common) derivative          :444-472
     double Ve, Ve_dc, Ve_dv;   // vascular fraction; d/dh == d/dc               :474-499
     double Ua, Ua_da;          // cytokine uptake                               :501-502
-    double dif_c, tax_c, dif_h, tax_h, dif_v, tax_v;  // thresholded transport  :504-509
   };
 
   template <int EXP_MODE>
@@ -163,9 +162,6 @@ struct Pihna {
     const double raK = rcp(s.a + k.Ka);
     s.Ua = s.a * raK;
     s.Ua_da = raK - s.Ua * raK;
-    s.dif_c = (s.c > k.Lambda ? k.dif_c : 0.0); s.tax_c = (s.c > k.Lambda ? k.tax_c : 0.0);
-    s.dif_h = (s.h > k.Lambda ? k.dif_h : 0.0); s.tax_h = (s.h > k.Lambda ? k.tax_h : 0.0);
-    s.dif_v = (s.v > k.Lambda ? k.dif_v : 0.0); s.tax_v = (s.v > k.Lambda ? k.tax_v : 0.0);
   }
 
   // coefficients of equation row `a` only would be enough for a row kernel, but the full set is
@@ -175,6 +171,10 @@ struct Pihna {
     const double T = k.DT2;
     const double oneVe = 1.0 - s.Ve;
     const double nVe_dc = -s.Ve_dc, nVe_dv = -s.Ve_dv;  // (-Ve__dc) etc. as written upstream
+    // thresholded transport coefficients, :504-509 (not stored in Pt: registers are scarcer than compares)
+    const double dif_c = (s.c > k.Lambda ? k.dif_c : 0.0), tax_c = (s.c > k.Lambda ? k.tax_c : 0.0);
+    const double dif_h = (s.h > k.Lambda ? k.dif_h : 0.0), tax_h = (s.h > k.Lambda ? k.tax_h : 0.0);
+    const double dif_v = (s.v > k.Lambda ? k.dif_v : 0.0), tax_v = (s.v > k.Lambda ? k.tax_v : 0.0);
     // ---- n equation, :514-522 and :571-597
     o.R[0] = s.n + T * (k.nec_c * s.c * s.n + k.nec_h * s.h * s.n + k.nec_v * s.v * s.n + k.h2n * oneVe * s.h);
     o.A[0][0] = 1.0 - T * (k.nec_c * s.c + k.nec_h * s.h + k.nec_v * s.v);
@@ -184,52 +184,52 @@ struct Pihna {
     // ---- c equation, :524-534 and :599-641   (gradient fields: 0 = c, 2 = v)
     const double pc = k.prod_c * s.dT * s.c;
     o.R[1] = s.c + T * (k.prod_c * s.Tau * s.c - k.c2h * oneVe * s.c + k.h2c * s.Ve * s.h - k.nec_c * s.c * s.n);
-    o.RG[1][0] = -T * s.dif_c * s.Tau;
-    o.RG[1][2] = -T * s.tax_c * s.Tau * s.c;
+    o.RG[1][0] = -T * dif_c * s.Tau;
+    o.RG[1][2] = -T * tax_c * s.Tau * s.c;
     o.A[1][0] = -T * (pc - k.nec_c * s.c);
     o.A[1][1] = 1.0 - T * (k.prod_c * s.Tau + pc - k.c2h * oneVe - k.c2h * nVe_dc * s.c + k.h2c * s.Ve_dc * s.h - k.nec_c * s.n);
     o.A[1][2] = -T * (pc - k.c2h * nVe_dc * s.c + k.h2c * s.Ve_dc * s.h + k.h2c * s.Ve);
     o.A[1][3] = -T * (pc - k.c2h * nVe_dv * s.c + k.h2c * s.Ve_dv * s.h);
     {
-      const double bc = T * s.dif_c * s.dT, bv = T * s.tax_c * s.dT * s.c;
+      const double bc = T * dif_c * s.dT, bv = T * tax_c * s.dT * s.c;
       for (int b = 0; b < 4; b++) { o.B[1][b][0] = bc; o.B[1][b][2] = bv; }
-      o.B[1][1][2] += T * s.tax_c * s.Tau;
+      o.B[1][1][2] += T * tax_c * s.Tau;
     }
-    o.D[1][1] = T * s.dif_c * s.Tau;
-    o.D[1][3] = T * s.tax_c * s.Tau * s.c;
+    o.D[1][1] = T * dif_c * s.Tau;
+    o.D[1][3] = T * tax_c * s.Tau * s.c;
     // ---- h equation, :536-546 and :643-684   (gradient fields: 1 = h, 2 = v)
     o.R[2] = s.h + T * (k.c2h * oneVe * s.c - k.h2c * s.Ve * s.h - k.nec_h * s.h * s.n - k.h2n * oneVe * s.h);
-    o.RG[2][1] = -T * s.dif_h * s.Tau;
-    o.RG[2][2] = -T * s.tax_h * s.Tau * s.h;
+    o.RG[2][1] = -T * dif_h * s.Tau;
+    o.RG[2][2] = -T * tax_h * s.Tau * s.h;
     o.A[2][0] = T * k.nec_h * s.h;
     o.A[2][1] = -T * (k.c2h * oneVe + k.c2h * nVe_dc * s.c - k.h2c * s.Ve_dc * s.h - k.h2n * nVe_dc * s.h);
     o.A[2][2] = 1.0 - T * (k.c2h * nVe_dc * s.c - k.h2c * s.Ve_dc * s.h - k.h2c * s.Ve - k.nec_h * s.n -
                            k.h2n * nVe_dc * s.h - k.h2n * oneVe);
     o.A[2][3] = -T * (k.c2h * nVe_dv * s.c - k.h2c * s.Ve_dv * s.h - k.h2n * nVe_dv * s.h);
     {
-      const double bh = T * s.dif_h * s.dT, bv = T * s.tax_h * s.dT * s.h;
+      const double bh = T * dif_h * s.dT, bv = T * tax_h * s.dT * s.h;
       for (int b = 0; b < 4; b++) { o.B[2][b][1] = bh; o.B[2][b][2] = bv; }
-      o.B[2][2][2] += T * s.tax_h * s.Tau;
+      o.B[2][2][2] += T * tax_h * s.Tau;
     }
-    o.D[2][2] = T * s.dif_h * s.Tau;
-    o.D[2][3] = T * s.tax_h * s.Tau * s.h;
+    o.D[2][2] = T * dif_h * s.Tau;
+    o.D[2][3] = T * tax_h * s.Tau * s.h;
     // ---- v equation, :548-556 and :686-724   (gradient fields: 2 = v, 3 = a)
     const double pv = k.prod_v * s.dT * s.Ua * s.v;
     o.R[3] = s.v + T * (k.prod_v * s.Tau * s.Ua * s.v - k.nec_v * s.v * s.n);
-    o.RG[3][2] = -T * s.dif_v * s.Tau;
-    o.RG[3][3] = -T * s.tax_v * s.Tau * s.v;
+    o.RG[3][2] = -T * dif_v * s.Tau;
+    o.RG[3][3] = -T * tax_v * s.Tau * s.v;
     o.A[3][0] = -T * (pv - k.nec_v * s.v);
     o.A[3][1] = -T * pv;
     o.A[3][2] = -T * pv;
     o.A[3][3] = 1.0 - T * (pv - k.nec_v * s.n);
     o.A[3][4] = -T * (k.prod_v * s.Tau * s.Ua_da * s.v);
     {
-      const double bv = T * s.dif_v * s.dT, ba = T * s.tax_v * s.dT * s.v;
+      const double bv = T * dif_v * s.dT, ba = T * tax_v * s.dT * s.v;
       for (int b = 0; b < 4; b++) { o.B[3][b][2] = bv; o.B[3][b][3] = ba; }
-      o.B[3][3][3] += T * s.tax_v * s.Tau;
+      o.B[3][3][3] += T * tax_v * s.Tau;
     }
-    o.D[3][3] = T * s.dif_v * s.Tau;
-    o.D[3][4] = T * s.tax_v * s.Tau * s.v;
+    o.D[3][3] = T * dif_v * s.Tau;
+    o.D[3][4] = T * tax_v * s.Tau * s.v;
     // ---- a equation, :558-566 and :726-747
     o.R[4] = s.a + T * (k.sec_c * s.c + k.sec_h * s.h - k.upt * s.v * s.a - k.dec * s.a);
     o.A[4][1] = -T * k.sec_c;

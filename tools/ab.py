@@ -52,4 +52,4 @@ for r in range(a.rounds):
 ne = conn.shape[0]
 for s in a.sets:
     v = np.array(res[s])
-    print(f"{s:40s} median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  -> {ne/np.median(v)/1e6:8.1f} Melem/s", flush=True)
+    print(f"{s:40s} median {np.median(v):8.3f} ms  min {v.min():8.3f} ms  -> {ne/np.median(v)/1e3:8.1f} Melem/s", flush=True)
