@@ -30,12 +30,13 @@ struct rdc_ctx {
   bool have_mesh = false;
   int strategy = RDC_SCATTER_AUTO;
   int variant = RDC_VARIANT_AUTO;
-  int opt_occ = 2, opt_ablate = 0;
+  int opt_occ = 2, opt_ablate = 0, opt_kernel = 0;
   HostPrep prep;
   // device mesh data
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
       wg_node_ptr;
   DevBuf val, rhs, packed;
+  DevBuf rg2_desc, rg2_pair, rg2_blk, rg2_contrib, rg2_node;
   DevBuf field[RDC_FIELD_COUNT];
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
   // solid
@@ -137,8 +138,9 @@ MeshDev mesh_view(const rdc_ctx* c) {
 
 int resolve_strategy(rdc_ctx* c, int* out) {
   int s = c->strategy;
-  if (s == RDC_SCATTER_AUTO) s = c->prep.rowgather_ok ? RDC_SCATTER_ROWGATHER : RDC_SCATTER_COLOURED;
-  if (s == RDC_SCATTER_ROWGATHER && !c->prep.rowgather_ok)
+  const bool rg = c->prep.rowgather_ok || (c->prep.rg2_ok && c->prep.nen == 4 && c->variant != RDC_VARIANT_GENERIC);
+  if (s == RDC_SCATTER_AUTO) s = rg ? RDC_SCATTER_ROWGATHER : RDC_SCATTER_COLOURED;
+  if (s == RDC_SCATTER_ROWGATHER && !rg)
     return fail(c, RDC_ERR_UNSUPPORTED, "row-gather scatter unavailable: a node row exceeds the LDS budget");
   *out = s;
   return RDC_OK;
@@ -183,6 +185,15 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.variant = c->variant;
   a.opt_occ = c->opt_occ;
   a.opt_ablate = c->opt_ablate;
+  a.opt_kernel = c->opt_kernel;
+  if (c->prep.rg2_ok && c->prep.nen == 4) {
+    a.rg2.n_wg = (int)c->prep.wg2.size();
+    a.rg2.desc = (const HostPrep::WgDesc*)c->rg2_desc.p;
+    a.rg2.pair_rec = (const uint32_t*)c->rg2_pair.p;
+    a.rg2.blk_info = (const HostPrep::BlkInfo*)c->rg2_blk.p;
+    a.rg2.contrib = (const uint16_t*)c->rg2_contrib.p;
+    a.rg2.node_info = (const uint32_t*)c->rg2_node.p;
+  }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
   a.stream = c->stream;
@@ -239,7 +250,8 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
-                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed,
+                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->rg2_desc, &c->rg2_pair, &c->rg2_blk,
+                   &c->rg2_contrib, &c->rg2_node,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
@@ -281,6 +293,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   if (!c || !key) return RDC_ERR_INVALID;
   if (!std::strcmp(key, "occupancy")) c->opt_occ = value;
   else if (!std::strcmp(key, "ablate")) c->opt_ablate = value;
+  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = staged row gather, 1 = LDS-atomic row gather
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
 }
@@ -318,6 +331,13 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   if ((rc = dev_upload(c, c->pair_local, P.pair_local))) return rc;
   if ((rc = dev_upload(c, c->node_pair_ptr, P.node_pair_ptr))) return rc;
   if ((rc = dev_upload(c, c->wg_node_ptr, P.wg_node_ptr))) return rc;
+  if (P.rg2_ok && elem_type == RDC_TET4) {
+    if ((rc = dev_upload(c, c->rg2_desc, P.wg2))) return rc;
+    if ((rc = dev_upload(c, c->rg2_pair, P.pair_rec))) return rc;
+    if ((rc = dev_upload(c, c->rg2_blk, P.blk_info))) return rc;
+    if ((rc = dev_upload(c, c->rg2_contrib, P.contrib))) return rc;
+    if ((rc = dev_upload(c, c->rg2_node, P.node_info))) return rc;
+  }
   const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
   if ((rc = dev_alloc(c, c->val, nnz * sizeof(double)))) return rc;
   if ((rc = dev_alloc(c, c->rhs, (size_t)n_owned * nvar * sizeof(double)))) return rc;

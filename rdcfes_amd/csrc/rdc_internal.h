@@ -13,6 +13,16 @@
 
 namespace rdc {
 
+// device view of the staged row-gather work lists (HostPrep::wg2 ...)
+struct Rg2Dev {
+  int n_wg = 0;
+  const HostPrep::WgDesc* desc = nullptr;
+  const uint32_t* pair_rec = nullptr;
+  const HostPrep::BlkInfo* blk_info = nullptr;
+  const uint16_t* contrib = nullptr;
+  const uint32_t* node_info = nullptr;
+};
+
 // ---- kernel launch plumbing -----------------------------------------------------------------
 struct LaunchArgs {
   MeshDev m;
@@ -21,7 +31,8 @@ struct LaunchArgs {
   const double* aux;
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
-  int opt_occ, opt_ablate;  // tuning knobs (rdc_set_option)
+  int opt_occ, opt_ablate, opt_kernel;  // tuning knobs (rdc_set_option)
+  Rg2Dev rg2;
   double* val;
   double* rhs;
   hipStream_t stream;

@@ -190,6 +190,88 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
     P.rg_lds_bytes = max_bytes;
     if (!P.rowgather_ok) { P.wg_node_ptr.assign(2, 0); P.wg_node_ptr[1] = 0; }
   }
+
+  // ---- staged row gather: workgroups of <= block pairs, flat descriptors, contribution lists ----
+  {
+    P.rg2_block = block;
+    P.rg2_ok = n_owned > 0;
+    std::vector<int64_t> wgp;  // node ranges
+    wgp.push_back(0);
+    int64_t pairs = 0;
+    for (int64_t n = 0; n < n_owned && P.rg2_ok; n++) {
+      const int64_t np = inc_ptr[n + 1] - inc_ptr[n];
+      const int64_t len = P.bptr[n + 1] - P.bptr[n];
+      if (np > block || np > 255 || len > 255) { P.rg2_ok = false; break; }
+      if (n > wgp.back() && pairs + np > block) { wgp.push_back(n); pairs = 0; }
+      pairs += np;
+    }
+    wgp.push_back(n_owned);
+    if (P.rg2_ok) {
+      const int64_t nwg = (int64_t)wgp.size() - 1;
+      P.wg2.resize((size_t)nwg);
+      P.pair_rec.assign((size_t)nwg * block * nen, 0xFFFFFFFFu);
+      P.blk_info.resize((size_t)P.bptr[n_owned]);
+      P.contrib.resize((size_t)inc_ptr[n_owned] * nen);
+      P.node_info.resize((size_t)n_owned);
+      std::vector<int32_t> fail_flag(1, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+      for (int64_t w = 0; w < nwg; w++) {
+        const int64_t n0 = wgp[w], n1 = wgp[w + 1];
+        HostPrep::WgDesc& d = P.wg2[w];
+        d.n0 = (int32_t)n0; d.nnodes = (int32_t)(n1 - n0);
+        d.bb0 = P.bptr[n0]; d.vb0 = (int64_t)nvar * nvar * d.bb0;
+        d.nb = (int32_t)(P.bptr[n1] - d.bb0);
+        d.np = (int32_t)(inc_ptr[n1] - inc_ptr[n0]);
+        d.c0 = inc_ptr[n0] * nen;
+        d.pad = 0;
+        // per block: counts, output offsets
+        for (int64_t n = n0; n < n1; n++) {
+          const int64_t len = P.bptr[n + 1] - P.bptr[n];
+          P.node_info[n] = (uint32_t)((inc_ptr[n] - inc_ptr[n0]) << 16) | (uint32_t)(inc_ptr[n + 1] - inc_ptr[n]);
+          for (int64_t s2 = 0; s2 < len; s2++) {
+            HostPrep::BlkInfo& b = P.blk_info[P.bptr[n] + s2];
+            const int64_t off = (int64_t)nvar * nvar * (P.bptr[n] - d.bb0) + nvar * s2;
+            if (off > 0xFFFF) fail_flag[0] = 1;
+            b.cbeg = 0; b.cnt = 0; b.len = (uint8_t)len; b.outoff = (uint16_t)off; b.pad = 0;
+          }
+        }
+        // pass 1: count contributions per block, write pair records
+        for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
+          const int64_t e = inc_elem[p];
+          const int i = inc_loc[p];
+          const int64_t I = conn[e * nen + i];
+          uint32_t* pr = &P.pair_rec[((size_t)w * block + (p - inc_ptr[n0])) * nen];
+          for (int j = 0; j < nen; j++) {
+            const int jo = (nen == 4) ? (j ^ i) : ((j + i) % nen);  // rotation: row node first
+            pr[j] = conn[e * nen + jo];
+            P.blk_info[P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo]].cnt++;
+          }
+        }
+        // prefix sums (contribution counts fit 8 bits: <= pairs per node <= 255)
+        int64_t run = 0;
+        for (int64_t b = d.bb0; b < d.bb0 + d.nb; b++) {
+          if (run > 0xFFFF) fail_flag[0] = 1;
+          P.blk_info[b].cbeg = (uint16_t)run;
+          run += P.blk_info[b].cnt;
+          P.blk_info[b].cnt = 0;
+        }
+        // pass 2: fill in ascending pair order -> fixed summation order, bitwise reproducible
+        for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
+          const int64_t e = inc_elem[p];
+          const int i = inc_loc[p];
+          const int64_t I = conn[e * nen + i];
+          for (int j = 0; j < nen; j++) {
+            const int jo = (nen == 4) ? (j ^ i) : ((j + i) % nen);
+            HostPrep::BlkInfo& b = P.blk_info[P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo]];
+            P.contrib[d.c0 + b.cbeg + b.cnt] = (uint16_t)((p - inc_ptr[n0]) * nen + j);
+            b.cnt++;
+          }
+        }
+      }
+      if (fail_flag[0]) P.rg2_ok = false;
+    }
+    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.blk_info.clear(); P.contrib.clear(); P.node_info.clear(); }
+  }
   return std::string();
 }
 

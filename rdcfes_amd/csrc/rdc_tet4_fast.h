@@ -22,11 +22,18 @@
 
 namespace rdc {
 
-// Sink interface:  void ke(int a, int b, int j, double v);   void fe(int a, double v);
-// j is the ROTATED local column index (original local index = j ^ irow).
-template <class M, int EXP_MODE, class Sink>
-RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const double (&U)[4][M::NV],
-                      const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Sink& sink) {
+// Element-level data shared by the five equation rows of one (row node, element) pair.
+template <class M>
+struct Tet4Pre {
+  double dd[4];            // grad phi_j . grad phi_0
+  double gk[M::NG];        // grad f_k . grad phi_0
+  double Wc, Wh;           // JxW at the centroid / at a hot point
+  typename M::Pt pt[5];    // point nonlinearities at c, h_0..h_3
+};
+
+template <class M, int EXP_MODE>
+RDC_HD void tet4_prepare(const typename M::K& k, const double (&X)[4][3], const double (&U)[4][M::NV],
+                         const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Tet4Pre<M>& P) {
   constexpr int NV = M::NV, NG = M::NG, NA = (M::NAUX > 0 ? M::NAUX : 1);
   // ---- geometry: grad phi_1..3 = cofactors / det, grad phi_0 = -(sum) ----------------------
   double e1[3], e2[3], e3[3];
@@ -45,14 +52,11 @@ RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const dou
   }
   // libMesh requires det > 0; fabs() only protects the rotated view of a valid element
   const double adet = fabs(det);
-  double dd[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) dd[j] = G[j][0] * G[0][0] + G[j][1] * G[0][1] + G[j][2] * G[0][2];
+  for (int j = 0; j < 4; j++) P.dd[j] = G[j][0] * G[0][0] + G[j][1] * G[0][1] + G[j][2] * G[0][2];
   // ---- constant gradient fields, projected on grad phi_0 ------------------------------------
-  double gk[NG];
 #pragma unroll
   for (int g = 0; g < NG; g++) {
-    constexpr int dummy = 0; (void)dummy;
     const int src = M::grad_src(g);
     double gf[3];
 #pragma unroll
@@ -67,79 +71,91 @@ RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const dou
       if (l2 != 0.0) { gf[0] /= l2; gf[1] /= l2; gf[2] /= l2; }
       else { gf[0] = 0.0; gf[1] = 0.0; gf[2] = 0.0; }
     }
-    gk[g] = gf[0] * G[0][0] + gf[1] * G[0][1] + gf[2] * G[0][2];
+    P.gk[g] = gf[0] * G[0][0] + gf[1] * G[0][1] + gf[2] * G[0][2];
   }
   // ---- point nonlinearities at c, h_0..h_3 (point index q: 0 = c, 1 + k = h_k) ---------------
-  typename M::Pt pt[5];
-  {
-    double S[NV], SA[NA];
+  double S[NV], SA[NA];
 #pragma unroll
-    for (int v = 0; v < NV; v++) S[v] = (U[0][v] + U[1][v]) + (U[2][v] + U[3][v]);
+  for (int v = 0; v < NV; v++) S[v] = (U[0][v] + U[1][v]) + (U[2][v] + U[3][v]);
 #pragma unroll
-    for (int v = 0; v < NA; v++) SA[v] = (AX[0][v] + AX[1][v]) + (AX[2][v] + AX[3][v]);
+  for (int v = 0; v < NA; v++) SA[v] = (AX[0][v] + AX[1][v]) + (AX[2][v] + AX[3][v]);
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
-      double uq[NV], aq[NA];
+  for (int q = 0; q < 5; q++) {
+    double uq[NV], aq[NA];
 #pragma unroll
-      for (int v = 0; v < NV; v++) uq[v] = (q == 0) ? 0.25 * S[v] : (S[v] * (1.0 / 6.0) + U[q == 0 ? 0 : q - 1][v] * (1.0 / 3.0));
+    for (int v = 0; v < NV; v++) uq[v] = (q == 0) ? 0.25 * S[v] : (S[v] * (1.0 / 6.0) + U[q == 0 ? 0 : q - 1][v] * (1.0 / 3.0));
 #pragma unroll
-      for (int v = 0; v < NA; v++) aq[v] = (q == 0) ? 0.25 * SA[v] : (SA[v] * (1.0 / 6.0) + AX[q == 0 ? 0 : q - 1][v] * (1.0 / 3.0));
-      M::template point<EXP_MODE>(k, uq, aq, pt[q]);
-    }
+    for (int v = 0; v < NA; v++) aq[v] = (q == 0) ? 0.25 * SA[v] : (SA[v] * (1.0 / 6.0) + AX[q == 0 ? 0 : q - 1][v] * (1.0 / 3.0));
+    M::template point<EXP_MODE>(k, uq, aq, P.pt[q]);
   }
+  P.Wc = adet * (-2.0 / 15.0);
+  P.Wh = adet * 0.075;
+}
+
+// Sink interface:  void ke(int a, int b, int j, double v);   void fe(int a, double v);
+// j is the ROTATED local column index (original local index = j ^ irow).
+// One equation row `a` of the pair (a is a compile-time constant after unrolling/inlining).
+template <class M, class Sink>
+RDC_HD void tet4_row(const typename M::K& k, const Tet4Pre<M>& P, int a, Sink& sink) {
+  constexpr int NV = M::NV, NG = M::NG;
   // JxW_q and JxW_q * phi_0(q)
-  const double Wc = adet * (-2.0 / 15.0), Wh = adet * 0.075;
-  const double W[5] = {Wc, Wh, Wh, Wh, Wh};
-  const double Om[5] = {Wc * 0.25, Wh * 0.5, Wh * (1.0 / 6.0), Wh * (1.0 / 6.0), Wh * (1.0 / 6.0)};
-  // ---- one equation row at a time -------------------------------------------------------------
+  const double W[5] = {P.Wc, P.Wh, P.Wh, P.Wh, P.Wh};
+  const double Om[5] = {P.Wc * 0.25, P.Wh * 0.5, P.Wh * (1.0 / 6.0), P.Wh * (1.0 / 6.0), P.Wh * (1.0 / 6.0)};
+  double T[NV], Dh[NV], mh[NV][4], fe = 0.0, rgh[NG];
 #pragma unroll
-  for (int a = 0; a < NV; a++) {
-    double T[NV], Dh[NV], mh[NV][4], fe = 0.0, rgh[NG];
+  for (int b = 0; b < NV; b++) { T[b] = 0.0; Dh[b] = 0.0; }
 #pragma unroll
-    for (int b = 0; b < NV; b++) { T[b] = 0.0; Dh[b] = 0.0; }
+  for (int g = 0; g < NG; g++) rgh[g] = 0.0;
 #pragma unroll
-    for (int g = 0; g < NG; g++) rgh[g] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      typename M::C c;
-      M::coef(k, pt[q], c);  // only row `a` is consumed; the rest is dead code
-      fe += Om[q] * c.R[a];
-#pragma unroll
-      for (int g = 0; g < NG; g++)
-        if (M::hasRG(a, g)) rgh[g] += W[q] * c.RG[a][g];
-#pragma unroll
-      for (int b = 0; b < NV; b++) {
-        double m = 0.0;
-        bool any = false;
-        if (M::hasA(a, b)) { m = Om[q] * c.A[a][b]; any = true; }
-        double beta = 0.0;
-        bool anyb = false;
-#pragma unroll
-        for (int g = 0; g < NG; g++)
-          if (M::hasB(a, b, g)) { beta += c.B[a][b][g] * gk[g]; anyb = true; }
-        if (anyb) { m += W[q] * beta; any = true; }
-        if (any) {
-          if (q == 0) T[b] += 0.25 * m;
-          else { T[b] += m * (1.0 / 6.0); mh[b][q == 0 ? 0 : q - 1] = m; }
-        } else if (q > 0) {
-          mh[b][q - 1] = 0.0;
-        }
-        if (M::hasD(a, b)) Dh[b] += W[q] * c.D[a][b];
-      }
-    }
+  for (int q = 0; q < 5; q++) {
+    typename M::C c;
+    M::coef(k, P.pt[q], c);  // only row `a` is consumed; the rest is dead code
+    fe += Om[q] * c.R[a];
 #pragma unroll
     for (int g = 0; g < NG; g++)
-      if (M::hasRG(a, g)) fe += rgh[g] * gk[g];
-    sink.fe(a, fe);
+      if (M::hasRG(a, g)) rgh[g] += W[q] * c.RG[a][g];
 #pragma unroll
-    for (int b = 0; b < NV; b++)
+    for (int b = 0; b < NV; b++) {
+      double m = 0.0;
+      bool any = false;
+      if (M::hasA(a, b)) { m = Om[q] * c.A[a][b]; any = true; }
+      double beta = 0.0;
+      bool anyb = false;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        double v = T[b] + mh[b][j] * (1.0 / 3.0);
-        if (M::hasD(a, b)) v += dd[j] * Dh[b];
-        sink.ke(a, b, j, v);
+      for (int g = 0; g < NG; g++)
+        if (M::hasB(a, b, g)) { beta += c.B[a][b][g] * P.gk[g]; anyb = true; }
+      if (anyb) { m += W[q] * beta; any = true; }
+      if (any) {
+        if (q == 0) T[b] += 0.25 * m;
+        else { T[b] += m * (1.0 / 6.0); mh[b][q == 0 ? 0 : q - 1] = m; }
+      } else if (q > 0) {
+        mh[b][q - 1] = 0.0;
       }
+      if (M::hasD(a, b)) Dh[b] += W[q] * c.D[a][b];
+    }
   }
+#pragma unroll
+  for (int g = 0; g < NG; g++)
+    if (M::hasRG(a, g)) fe += rgh[g] * P.gk[g];
+  sink.fe(a, fe);
+#pragma unroll
+  for (int b = 0; b < NV; b++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double v = T[b] + mh[b][j] * (1.0 / 3.0);
+      if (M::hasD(a, b)) v += P.dd[j] * Dh[b];
+      sink.ke(a, b, j, v);
+    }
+}
+
+// all rows of the pair
+template <class M, int EXP_MODE, class Sink>
+RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const double (&U)[4][M::NV],
+                      const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Sink& sink) {
+  Tet4Pre<M> P;
+  tet4_prepare<M, EXP_MODE>(k, X, U, AX, P);
+#pragma unroll
+  for (int a = 0; a < M::NV; a++) tet4_row<M>(k, P, a, sink);
 }
 
 }  // namespace rdc
