@@ -36,7 +36,7 @@ struct rdc_ctx {
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
       wg_node_ptr;
   DevBuf val, rhs, packed;
-  DevBuf rg2_desc, rg2_pair, rg2_blk, rg2_contrib, rg2_node;
+  DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux;
   DevBuf field[RDC_FIELD_COUNT];
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
   // solid
@@ -190,9 +190,11 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.n_wg = (int)c->prep.wg2.size();
     a.rg2.desc = (const HostPrep::WgDesc*)c->rg2_desc.p;
     a.rg2.pair_rec = (const uint32_t*)c->rg2_pair.p;
-    a.rg2.blk_info = (const HostPrep::BlkInfo*)c->rg2_blk.p;
+    a.rg2.chunk = (const HostPrep::Chunk*)c->rg2_chunk.p;
+    a.rg2.sdesc = (const HostPrep::StoreDesc*)c->rg2_sdesc.p;
     a.rg2.contrib = (const uint16_t*)c->rg2_contrib.p;
-    a.rg2.node_info = (const uint32_t*)c->rg2_node.p;
+    a.rg2.pair_aux = (const uint16_t*)c->rg2_aux.p;
+    a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
   }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
@@ -250,8 +252,8 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
-                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->rg2_desc, &c->rg2_pair, &c->rg2_blk,
-                   &c->rg2_contrib, &c->rg2_node,
+                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
+                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
@@ -293,7 +295,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   if (!c || !key) return RDC_ERR_INVALID;
   if (!std::strcmp(key, "occupancy")) c->opt_occ = value;
   else if (!std::strcmp(key, "ablate")) c->opt_ablate = value;
-  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = staged row gather, 1 = LDS-atomic row gather
+  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = flat-list LDS row gather, 1 = first row-gather kernel, 2 = staged (deterministic) row gather
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
 }
@@ -334,9 +336,10 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   if (P.rg2_ok && elem_type == RDC_TET4) {
     if ((rc = dev_upload(c, c->rg2_desc, P.wg2))) return rc;
     if ((rc = dev_upload(c, c->rg2_pair, P.pair_rec))) return rc;
-    if ((rc = dev_upload(c, c->rg2_blk, P.blk_info))) return rc;
+    if ((rc = dev_upload(c, c->rg2_chunk, P.chunk))) return rc;
+    if ((rc = dev_upload(c, c->rg2_sdesc, P.sdesc))) return rc;
     if ((rc = dev_upload(c, c->rg2_contrib, P.contrib))) return rc;
-    if ((rc = dev_upload(c, c->rg2_node, P.node_info))) return rc;
+    if ((rc = dev_upload(c, c->rg2_aux, P.pair_aux))) return rc;
   }
   const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
   if ((rc = dev_alloc(c, c->val, nnz * sizeof(double)))) return rc;

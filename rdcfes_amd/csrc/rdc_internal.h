@@ -18,9 +18,11 @@ struct Rg2Dev {
   int n_wg = 0;
   const HostPrep::WgDesc* desc = nullptr;
   const uint32_t* pair_rec = nullptr;
-  const HostPrep::BlkInfo* blk_info = nullptr;
+  const HostPrep::Chunk* chunk = nullptr;
+  const HostPrep::StoreDesc* sdesc = nullptr;
   const uint16_t* contrib = nullptr;
-  const uint32_t* node_info = nullptr;
+  const uint16_t* pair_aux = nullptr;
+  size_t lds_bytes = 0;
 };
 
 // ---- kernel launch plumbing -----------------------------------------------------------------

@@ -191,29 +191,70 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
     if (!P.rowgather_ok) { P.wg_node_ptr.assign(2, 0); P.wg_node_ptr[1] = 0; }
   }
 
-  // ---- staged row gather: workgroups of <= block pairs, flat descriptors, contribution lists ----
+  // ---- staged row gather: workgroups of <= block pairs, flat descriptors, balanced chunks ------
   {
+    constexpr int CH = HostPrep::RG2_CHUNK;
     P.rg2_block = block;
     P.rg2_ok = n_owned > 0;
+    // contributions per node block (= elements containing the edge / all incident elements on the
+    // diagonal); needed up front to size the workgroups
+    std::vector<uint8_t> bcnt((size_t)P.bptr[n_owned], 0);
+    for (int64_t p = 0; p < inc_ptr[n_owned] && P.rg2_ok; p++) {
+      const int64_t e = inc_elem[p];
+      const int i = inc_loc[p];
+      const int64_t I = conn[e * nen + i];
+      for (int jo = 0; jo < nen; jo++) {
+        uint8_t& c = bcnt[P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo]];
+        if (c == 255) { P.rg2_ok = false; break; }
+        c++;
+      }
+    }
     std::vector<int64_t> wgp;  // node ranges
     wgp.push_back(0);
-    int64_t pairs = 0;
+    int64_t pairs = 0, chunks = 0;
+    size_t bytes = 0, max_bytes = 0;
     for (int64_t n = 0; n < n_owned && P.rg2_ok; n++) {
       const int64_t np = inc_ptr[n + 1] - inc_ptr[n];
       const int64_t len = P.bptr[n + 1] - P.bptr[n];
-      if (np > block || np > 255 || len > 255) { P.rg2_ok = false; break; }
-      if (n > wgp.back() && pairs + np > block) { wgp.push_back(n); pairs = 0; }
+      const size_t nbytes = sizeof(double) * ((size_t)nvar * nvar * len + nvar);
+      if (nbytes > lds_budget_bytes) { P.rg2_ok = false; break; }
+      int64_t nch = 0;
+      for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) nch += std::max<int64_t>(1, (bcnt[b] + CH - 1) / CH);
+      if (np > block || nch + 1 > block || len > 255) { P.rg2_ok = false; break; }
+      // gather work items of a workgroup: its chunks plus one rhs item per node
+      if (n > wgp.back() && (pairs + np > block || chunks + nch + (n - wgp.back() + 1) > block || n - wgp.back() >= 255 ||
+                             bytes + nbytes > lds_budget_bytes)) {
+        wgp.push_back(n);
+        pairs = 0;
+        chunks = 0;
+        bytes = 0;
+      }
       pairs += np;
+      chunks += nch;
+      bytes += nbytes;
+      max_bytes = std::max(max_bytes, bytes);
     }
+    P.rg2_lds_bytes = max_bytes;
     wgp.push_back(n_owned);
     if (P.rg2_ok) {
       const int64_t nwg = (int64_t)wgp.size() - 1;
+      // stage row of a pair: [column 0 (diagonal block): nvar values][rhs value][columns 1..nen-1: nvar each];
+      // odd padding keeps ds_write_b64 conflict-free
+      const int stride = (nen * nvar + 1) | 1;
       P.wg2.resize((size_t)nwg);
       P.pair_rec.assign((size_t)nwg * block * nen, 0xFFFFFFFFu);
-      P.blk_info.resize((size_t)P.bptr[n_owned]);
-      P.contrib.resize((size_t)inc_ptr[n_owned] * nen);
-      P.node_info.resize((size_t)n_owned);
-      std::vector<int32_t> fail_flag(1, 0);
+      if (nen == 4) P.pair_aux.assign((size_t)nwg * block * 8, 0);
+      P.sdesc.resize((size_t)P.bptr[n_owned]);
+      P.contrib.assign((size_t)inc_ptr[n_owned] * nen + (size_t)block * nen, 0);  // tail pad: vector loads may overrun
+      // chunk offsets per workgroup
+      std::vector<int64_t> ch0((size_t)nwg + 1, 0);
+      for (int64_t w = 0; w < nwg; w++) {
+        int64_t nch = 0;
+        for (int64_t b = P.bptr[wgp[w]]; b < P.bptr[wgp[w + 1]]; b++) nch += std::max<int64_t>(1, (bcnt[b] + CH - 1) / CH);
+        ch0[w + 1] = ch0[w] + nch;
+      }
+      P.chunk.resize((size_t)ch0[nwg]);
+      int fail_flag = 0;
 #pragma omp parallel for schedule(dynamic, 256)
       for (int64_t w = 0; w < nwg; w++) {
         const int64_t n0 = wgp[w], n1 = wgp[w + 1];
@@ -223,54 +264,70 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         d.nb = (int32_t)(P.bptr[n1] - d.bb0);
         d.np = (int32_t)(inc_ptr[n1] - inc_ptr[n0]);
         d.c0 = inc_ptr[n0] * nen;
+        d.ch0 = ch0[w];
+        d.nch = (int32_t)(ch0[w + 1] - ch0[w]);
         d.pad = 0;
-        // per block: counts, output offsets
+        // contribution ranges per block (prefix of bcnt), chunks, store descriptors
+        std::vector<int32_t> cbeg((size_t)d.nb + 1, 0), fill((size_t)d.nb, 0);
+        for (int b = 0; b < d.nb; b++) cbeg[b + 1] = cbeg[b] + bcnt[d.bb0 + b];
+        int64_t ck = d.ch0;
+        int extra = d.nb;  // partial-sum slots: [0, nb) one per block, then the extra chunks
         for (int64_t n = n0; n < n1; n++) {
           const int64_t len = P.bptr[n + 1] - P.bptr[n];
-          P.node_info[n] = (uint32_t)((inc_ptr[n] - inc_ptr[n0]) << 16) | (uint32_t)(inc_ptr[n + 1] - inc_ptr[n]);
           for (int64_t s2 = 0; s2 < len; s2++) {
-            HostPrep::BlkInfo& b = P.blk_info[P.bptr[n] + s2];
+            const int64_t gb = P.bptr[n] + s2;
+            const int lb = (int)(gb - d.bb0);
+            HostPrep::StoreDesc& sd = P.sdesc[gb];
             const int64_t off = (int64_t)nvar * nvar * (P.bptr[n] - d.bb0) + nvar * s2;
-            if (off > 0xFFFF) fail_flag[0] = 1;
-            b.cbeg = 0; b.cnt = 0; b.len = (uint8_t)len; b.outoff = (uint16_t)off; b.pad = 0;
+            if (off > 0xFFFF) fail_flag = 1;
+            sd.outoff = (uint16_t)off; sd.len = (uint8_t)len;
+            sd.diag = (P.bcol[gb] == (int32_t)n) ? 1 : 0;
+            sd.node = (uint8_t)(n - n0);
+            const int cnt = bcnt[gb];
+            const int nch = std::max(1, (cnt + CH - 1) / CH);
+            sd.nextra = (uint8_t)(nch - 1);
+            sd.extra = (uint16_t)extra;
+            for (int c = 0; c < nch; c++) {
+              HostPrep::Chunk& k = P.chunk[ck++];
+              k.cbeg = (uint16_t)(cbeg[lb] + c * CH);
+              k.cnt = (uint16_t)std::min(CH, cnt - c * CH);
+              if (cnt == 0) k.cnt = 0;
+              k.dst = (uint16_t)(c == 0 ? lb : extra++);
+              k.pad = 0;
+            }
           }
         }
-        // pass 1: count contributions per block, write pair records
+        d.nout = extra;
+        if (extra > block) fail_flag = 1;
+        // pair records and contribution entries in ascending pair order -> fixed summation order
         for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
           const int64_t e = inc_elem[p];
           const int i = inc_loc[p];
           const int64_t I = conn[e * nen + i];
-          uint32_t* pr = &P.pair_rec[((size_t)w * block + (p - inc_ptr[n0])) * nen];
+          const int64_t idx = p - inc_ptr[n0];
+          uint32_t* pr = &P.pair_rec[((size_t)w * block + idx) * nen];
+          if (nen == 4) {
+            uint16_t* ax = &P.pair_aux[((size_t)w * block + idx) * 8];
+            const int64_t len = P.bptr[I + 1] - P.bptr[I];
+            const int64_t rowoff = (int64_t)nvar * nvar * (P.bptr[I] - d.bb0);
+            if (rowoff > 0xFFFF) fail_flag = 1;
+            ax[0] = (uint16_t)rowoff;
+            ax[1] = (uint16_t)(nvar * len);
+            ax[2] = (uint16_t)((I - n0) * nvar);
+            ax[3] = 0;
+            for (int j = 0; j < 4; j++) ax[4 + j] = (uint16_t)(nvar * P.eslot[(size_t)e * 16 + i * 4 + (j ^ i)]);
+          }
           for (int j = 0; j < nen; j++) {
             const int jo = (nen == 4) ? (j ^ i) : ((j + i) % nen);  // rotation: row node first
             pr[j] = conn[e * nen + jo];
-            P.blk_info[P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo]].cnt++;
-          }
-        }
-        // prefix sums (contribution counts fit 8 bits: <= pairs per node <= 255)
-        int64_t run = 0;
-        for (int64_t b = d.bb0; b < d.bb0 + d.nb; b++) {
-          if (run > 0xFFFF) fail_flag[0] = 1;
-          P.blk_info[b].cbeg = (uint16_t)run;
-          run += P.blk_info[b].cnt;
-          P.blk_info[b].cnt = 0;
-        }
-        // pass 2: fill in ascending pair order -> fixed summation order, bitwise reproducible
-        for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
-          const int64_t e = inc_elem[p];
-          const int i = inc_loc[p];
-          const int64_t I = conn[e * nen + i];
-          for (int j = 0; j < nen; j++) {
-            const int jo = (nen == 4) ? (j ^ i) : ((j + i) % nen);
-            HostPrep::BlkInfo& b = P.blk_info[P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo]];
-            P.contrib[d.c0 + b.cbeg + b.cnt] = (uint16_t)((p - inc_ptr[n0]) * nen + j);
-            b.cnt++;
+            const int lb = (int)(P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo] - d.bb0);
+            P.contrib[d.c0 + cbeg[lb] + fill[lb]++] = (uint16_t)(idx * stride + (j == 0 ? 0 : j * nvar + 1));
           }
         }
       }
-      if (fail_flag[0]) P.rg2_ok = false;
+      if (fail_flag) P.rg2_ok = false;
     }
-    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.blk_info.clear(); P.contrib.clear(); P.node_info.clear(); }
+    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); }
   }
   return std::string();
 }

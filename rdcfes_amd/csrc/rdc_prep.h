@@ -33,29 +33,43 @@ struct HostPrep {
   std::vector<int64_t> node_pair_ptr;
   std::vector<int32_t> wg_node_ptr;
   // staged row gather ("rg2"): flat per-workgroup descriptors so the kernel needs only two
-  // dependent load levels, and contribution lists for the deterministic LDS gather
-  struct WgDesc {          // 48 bytes
+  // dependent load levels, and balanced contribution chunks for the deterministic LDS gather
+  struct WgDesc {          // 64 bytes
     int64_t vb0;           // first CSR value of the workgroup's rows  (nvar^2 * bptr[n0])
     int64_t bb0;           // first node block                        (bptr[n0])
     int64_t c0;            // first entry in `contrib`
+    int64_t ch0;           // first entry in `chunk`
     int32_t n0, nnodes;    // owned nodes [n0, n0 + nnodes)
     int32_t nb, np;        // node blocks and (node, element) pairs of the workgroup
+    int32_t nch, nout;     // gather chunks; partial-sum slots (blocks + extra chunks of split lists)
     int64_t pad;
   };
-  struct BlkInfo {         // 8 bytes, one per node block
+  struct Chunk {           // 8 bytes: one gather work item = <= RG2_CHUNK contributions to one block
     uint16_t cbeg;         // first contribution (relative to WgDesc::c0)
-    uint8_t cnt;           // number of contributions
-    uint8_t len;           // blocks in the row of the owner node
-    uint16_t outoff;       // value offset of (a = 0, b = 0) relative to vb0
+    uint16_t cnt;
+    uint16_t dst;          // partial-sum slot (in units of nvar doubles)
     uint16_t pad;
   };
+  struct StoreDesc {       // 8 bytes, one per node block
+    uint16_t outoff;       // value offset of (a = 0, b = 0) relative to vb0
+    uint8_t len;           // blocks in the row of the owner node
+    uint8_t nextra;        // extra partial-sum slots to add (lists longer than one chunk)
+    uint16_t extra;        // first extra slot
+    uint8_t diag;          // 1 for the diagonal block of its node: its slot also carries the rhs sum
+    uint8_t node;          // owner node index within the workgroup
+  };
+  static constexpr int RG2_CHUNK = 6;
   bool rg2_ok = false;
   int rg2_block = 256;
   std::vector<WgDesc> wg2;
   std::vector<uint32_t> pair_rec;   // [n_wg][block][nen] node ids, row node first (TET4: j -> j ^ i); ~0u = no pair
-  std::vector<BlkInfo> blk_info;    // [total node blocks]
-  std::vector<uint16_t> contrib;    // pair_index * nen + rotated column
-  std::vector<uint32_t> node_info;  // [n_owned] (first pair within the workgroup) << 16 | pair count
+  // per pair, for the LDS-accumulating kernel: offsets inside the workgroup's row slice (doubles):
+  // {rowoff, stride = nvar*len, rhsoff, pad, off[0..3] = nvar*slot of rotated column j}  (TET4 only)
+  std::vector<uint16_t> pair_aux;   // [n_wg][block][8]
+  size_t rg2_lds_bytes = 0;         // largest row slice (values + rhs) of a workgroup
+  std::vector<Chunk> chunk;
+  std::vector<StoreDesc> sdesc;     // [total node blocks]
+  std::vector<uint16_t> contrib;    // stage index (doubles) of the contribution: pair * stride + slot(column), see rdc_meshprep.cpp
 };
 
 // returns empty string on success, else an error message

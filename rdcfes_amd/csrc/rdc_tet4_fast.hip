@@ -138,6 +138,53 @@ k_tet4_rowgather(const MeshDev m, const typename M::K k, const double* __restric
   for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
 }
 
+// ---- row gather, flat work lists ------------------------------------------------------------
+// Same algorithm as k_tet4_rowgather, but everything a thread needs comes from one workgroup
+// descriptor and one 32-byte pair record that are addressed by blockIdx / threadIdx alone, so the
+// dependent load chain is two levels deep (descriptor | pair record -> node records) instead of
+// five (wg_node_ptr -> bptr / node_pair_ptr -> pair_elem -> conn / eslot -> records, bptr[I]).
+template <class M, int EXP_MODE, int BLOCK, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW)
+k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_rec,
+           const uint16_t* __restrict__ pair_aux, const typename M::K k, const double* __restrict__ rec,
+           double* __restrict__ val, double* __restrict__ rhs) {
+  constexpr int NV = M::NV, NW = BLOCK / 64;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int w = blockIdx.x;
+  // lane l of wave v takes pair l*NW + v (spreads the pairs of one node over the waves)
+  const int idx = (threadIdx.x & 63) * NW + (threadIdx.x >> 6);
+  const uint4 pr = reinterpret_cast<const uint4*>(pair_rec)[(int64_t)w * BLOCK + idx];
+  const uint4 ax = reinterpret_cast<const uint4*>(pair_aux)[(int64_t)w * BLOCK + idx];
+  const HostPrep::WgDesc d = desc[w];
+  const bool valid = pr.x != 0xFFFFFFFFu;
+  double X[4][3], U[4][NV], AX[4][M::NAUX > 0 ? M::NAUX : 1];
+  if (valid) {
+    load_rec<M>(rec, pr.x, X[0], U[0], AX[0]);
+    load_rec<M>(rec, pr.y, X[1], U[1], AX[1]);
+    load_rec<M>(rec, pr.z, X[2], U[2], AX[2]);
+    load_rec<M>(rec, pr.w, X[3], U[3], AX[3]);
+  }
+  // zero the row slice while the loads are in flight
+  const int nval = d.nb * NV * NV, nrhs = d.nnodes * NV;
+  for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
+  __syncthreads();
+  if (valid) {
+    LdsSink<M, 0> sink;
+    sink.dummy = 0.0;
+    sink.row = lds + (ax.x & 0xFFFF);
+    sink.stride = (int)(ax.x >> 16);
+    sink.lrhs = lds + nval + (ax.y & 0xFFFF);
+    sink.off[0] = (int)(ax.z & 0xFFFF); sink.off[1] = (int)(ax.z >> 16);
+    sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
+    tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
+  }
+  __syncthreads();
+  double* out = val + d.vb0;
+  for (int x = threadIdx.x; x < nval; x += BLOCK) __builtin_nontemporal_store(lds[x], out + x);
+  double* orhs = rhs + (int64_t)d.n0 * NV;
+  for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lds[nval + x];
+}
+
 // ---- staged row gather (the default TET4 path) ----------------------------------------------
 // One thread per (row node, incident element) pair evaluates one equation row at a time into an
 // LDS stage buffer with plain stores; after a barrier the same workgroup sums, for every node
@@ -145,22 +192,27 @@ k_tet4_rowgather(const MeshDev m, const typename M::K k, const double* __restric
 // the CSR values straight to HBM with streaming stores.  Compared with k_tet4_rowgather: no LDS
 // atomics (an FP64 ds_add costs ~45 issue cycles on gfx950), no LDS row slice, no zero / flush
 // passes, and only two dependent load levels (descriptor | pair record  ->  node records).
+// stage row of a pair: [column 0 = diagonal block: NV values][rhs value][columns 1..3: NV values each]
 struct StageSink {
   double* my;  // stage row of this thread
-  __device__ __forceinline__ void ke(int, int b, int j, double v) { my[j * NVs + b] = v; }
-  __device__ __forceinline__ void fe(int, double v) { my[4 * NVs] = v; }
+  __device__ __forceinline__ void ke(int, int b, int j, double v) { my[j == 0 ? b : j * NVs + 1 + b] = v; }
+  __device__ __forceinline__ void fe(int, double v) { my[NVs] = v; }
   int NVs;
 };
 
 template <class M, int EXP_MODE, int BLOCK, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW)
 k_tet4_rg2(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_rec,
-           const HostPrep::BlkInfo* __restrict__ blk_info, const uint16_t* __restrict__ contrib,
-           const uint32_t* __restrict__ node_info, const typename M::K k, const double* __restrict__ rec,
-           double* __restrict__ val, double* __restrict__ rhs) {
-  constexpr int NV = M::NV, STRIDE = 4 * NV + 1;  // odd stride: conflict-free ds_write_b64
+           const HostPrep::Chunk* __restrict__ chunk, const HostPrep::StoreDesc* __restrict__ sdesc,
+           const uint16_t* __restrict__ contrib, const typename M::K k, const double* __restrict__ rec,
+           double* __restrict__ val, double* __restrict__ rhs, const int dbg) {
+  constexpr int NV = M::NV, STRIDE = (4 * NV + 1) | 1, SLOT = NV + 1;  // odd stride: conflict-free ds_write_b64
   __shared__ double stage[BLOCK * STRIDE];
-  __shared__ uint16_t clist[BLOCK * 4];
+  __shared__ double outbuf[BLOCK * SLOT];  // partial sums of one row pass: NV values + rhs per slot, nout <= BLOCK
+  __shared__ uint2 clist2[BLOCK];          // 4 contribution entries (uint16) per pair
+  __shared__ uint2 lchunk[BLOCK];
+  __shared__ uint2 lsdesc[BLOCK];
+  const uint16_t* clist = reinterpret_cast<const uint16_t*>(clist2);
   const int w = blockIdx.x, tid = threadIdx.x;
   // level-1 loads: independent of each other
   const uint4 pr = reinterpret_cast<const uint4*>(pair_rec)[(int64_t)w * BLOCK + tid];
@@ -176,45 +228,54 @@ k_tet4_rg2(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     load_rec<M>(rec, pr.w, X[3], U[3], AX[3]);
     tet4_prepare<M, EXP_MODE>(k, X, U, AX, P);
   }
-  for (int x = tid; x < d.np * 4; x += BLOCK) clist[x] = contrib[d.c0 + x];
-  const int nitems = d.nb + d.nnodes;  // gather items: node blocks, then rhs entries of the nodes
+  if (tid < d.np) clist2[tid] = reinterpret_cast<const uint2*>(contrib + d.c0)[tid];
+  if (tid < d.nch) lchunk[tid] = reinterpret_cast<const uint2*>(chunk)[d.ch0 + tid];
+  if (tid < d.nb) lsdesc[tid] = reinterpret_cast<const uint2*>(sdesc)[d.bb0 + tid];
+  const int nvals = d.nb * NV;
   StageSink sink;
   sink.my = stage + tid * STRIDE;
   sink.NVs = NV;
 #pragma unroll
   for (int a = 0; a < NV; a++) {
     // launder the time-step factor: every coefficient of the row depends on it, so the compiler
-    // cannot hoist row a's arithmetic above the previous barrier (which would keep all five rows'
-    // temporaries alive at once and cost ~140 registers)
+    // cannot hoist row a's arithmetic above the previous barrier
     typename M::K kk = k;
     asm volatile("" : "+s"(kk.DT2));
-    if (valid) tet4_row<M>(kk, P, a, sink);
+    if (valid && !(dbg & 1)) tet4_row<M>(kk, P, a, sink);
     __syncthreads();
-    for (int g = tid; g < nitems; g += BLOCK) {
-      if (g < d.nb) {
-        const HostPrep::BlkInfo bi = blk_info[d.bb0 + g];
-        double acc[NV];
+    // ---- gather: one chunk (<= RG2_CHUNK contributions to one node block) per thread ----------
+    if (tid < d.nch && !(dbg & 2)) {
+      const uint2 c = lchunk[tid];  // {cbeg | cnt << 16, dst}
+      const int cbeg = c.x & 0xFFFF, cnt = c.x >> 16, dst = c.y & 0xFFFF;
+      double acc[SLOT];
 #pragma unroll
-        for (int b = 0; b < NV; b++) acc[b] = 0.0;
-        for (int c = 0; c < bi.cnt; c++) {
-          const int e = clist[bi.cbeg + c];
-          const double* src = stage + (e >> 2) * STRIDE + (e & 3) * NV;
+      for (int b = 0; b < SLOT; b++) acc[b] = 0.0;
 #pragma unroll
-          for (int b = 0; b < NV; b++) acc[b] += src[b];
+      for (int x = 0; x < HostPrep::RG2_CHUNK; x++)
+        if (x < cnt) {
+          const double* src = stage + clist[cbeg + x];
+#pragma unroll
+          for (int b = 0; b < SLOT; b++) acc[b] += src[b];  // 6th value: rhs (meaningful for diagonal blocks only)
         }
-        double* out = val + d.vb0 + bi.outoff + a * NV * (int)bi.len;
 #pragma unroll
-        for (int b = 0; b < NV; b++) __builtin_nontemporal_store(acc[b], out + b);
-      } else {
-        const int i = g - d.nb;
-        const uint32_t ni = node_info[d.n0 + i];
-        const int pbeg = ni >> 16, pcnt = ni & 0xFFFF;
-        double acc = 0.0;
-        for (int c = 0; c < pcnt; c++) acc += stage[(pbeg + c) * STRIDE + 4 * NV];
-        rhs[(int64_t)(d.n0 + i) * NV + a] = acc;
-      }
+      for (int b = 0; b < SLOT; b++) outbuf[dst * SLOT + b] = acc[b];
     }
     __syncthreads();
+    // ---- store: consecutive threads -> consecutive CSR values, streaming stores -----------------
+    for (int x = tid; x < nvals && !(dbg & 4); x += BLOCK) {
+      const int ob = x / NV, b = x - ob * NV;
+      const uint2 sd = lsdesc[ob];  // {outoff | len << 16 | nextra << 24, extra | diag << 16 | node << 24}
+      const int outoff = sd.x & 0xFFFF, len = (sd.x >> 16) & 0xFF, nextra = sd.x >> 24, extra = sd.y & 0xFFFF;
+      double v = outbuf[ob * SLOT + b];
+      for (int e = 0; e < nextra; e++) v += outbuf[(extra + e) * SLOT + b];
+      __builtin_nontemporal_store(v, val + d.vb0 + outoff + a * NV * len + b);
+      if (b == 0 && ((sd.y >> 16) & 0xFF)) {  // diagonal block: its slot also carries the node's rhs entry
+        double r = outbuf[ob * SLOT + NV];
+        for (int e = 0; e < nextra; e++) r += outbuf[(extra + e) * SLOT + NV];
+        rhs[(int64_t)(d.n0 + (int)(sd.y >> 24)) * NV + a] = r;
+      }
+    }
+    // (the next barrier, after the next row's compute, orders these outbuf reads before its reuse)
   }
 }
 
@@ -281,11 +342,22 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
-  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.opt_kernel != 1) {
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.opt_kernel == 0) {
+    constexpr int BLOCK = 256;
+#define RDC_RG3(MINW)                                                                                              \
+  hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
+                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, k, a.packed, a.val, a.rhs)
+    if (a.opt_occ == 1) RDC_RG3(1);
+    else if (a.opt_occ == 3) RDC_RG3(3);
+    else RDC_RG3(2);
+#undef RDC_RG3
+    return hipGetLastError();
+  }
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.opt_kernel == 2) {
     constexpr int BLOCK = 256;
 #define RDC_RG2(MINW)                                                                                              \
   hipLaunchKernelGGL((k_tet4_rg2<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), 0, a.stream, a.rg2.desc, \
-                     a.rg2.pair_rec, a.rg2.blk_info, a.rg2.contrib, a.rg2.node_info, k, a.packed, a.val, a.rhs)
+                     a.rg2.pair_rec, a.rg2.chunk, a.rg2.sdesc, a.rg2.contrib, k, a.packed, a.val, a.rhs, a.opt_ablate)
     if (a.opt_occ == 1) RDC_RG2(1);
     else if (a.opt_occ == 3) RDC_RG2(3);
     else RDC_RG2(2);

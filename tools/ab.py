@@ -40,7 +40,7 @@ ctx.timing_enable(True)
 res = {s: [] for s in a.sets}
 for r in range(a.rounds):
     for s in a.sets:
-        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0)
+        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0)
         for kv in s.split(","):
             if "=" in kv:
                 k, v = kv.split("="); ctx.set_option(k, int(v))
