@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--scatter", default="auto", choices=["auto", "coloured", "rowgather"])
     ap.add_argument("--variant", default="auto", choices=["auto", "generic"])
     ap.add_argument("--order", default="lex", choices=["lex", "random"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production); gloo = host-staged halo, for rehearsing N > 1 on a 1-GPU box")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (rdc_set_option)")
     ap.add_argument("--cpu-sample", type=int, default=60, help="K(m) sample for the CPU baseline (0 = skip)")
     a = ap.parse_args()
@@ -79,11 +81,15 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the assembly path is HIP-only (no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     conn, xyz = synth.kuhn_tet_mesh(a.n, order=a.order)
     u = synth.pihna_fields(xyz)
@@ -132,7 +138,7 @@ def main():
     kern_ms, n_calls = ctx.timing_sum_ms()
     ctx.timing_enable(False)
     if world > 1:
-        t = torch.tensor([dt, kern_ms / max(n_calls, 1)], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, kern_ms / max(n_calls, 1)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_avg_ms = float(t[0]), float(t[1])
     else:
@@ -157,7 +163,7 @@ def main():
             "config": {"workload": f"PIHNA TET4 K({a.n}): {n_elem_global} tets, {n_node_global} nodes, 5 unknowns, "
                                    f"params run/PIHNA/input.dat ({a.params}), order={a.order}",
                        "scatter": ["auto", "coloured", "rowgather"][ctx.get_scatter()], "kernel_variant": a.variant, "options": a.opt,
-                       "parallelism": f"element partition x{world}, 1 ghost layer, halo p2p over RCCL" if world > 1 else "single GPU",
+                       "parallelism": (f"element partition x{world}, 1 ghost layer, halo p2p over " + ("RCCL" if a.backend == "nccl" else "gloo (host-staged rehearsal)")) if world > 1 else "single GPU",
                        "rank0_local_elements": int(l_conn.shape[0]), "rank0_nnz": int(nnz)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -99,6 +99,7 @@ struct Pihna {
   using C = Coef<NV, NG>;
   // which nodal array feeds gradient field k: index into u (>=0)
   RDC_HD static constexpr int grad_src(int k) { return k + 1; }
+  RDC_HD static constexpr int row_order(int x) { return x; }
   // structural sparsity of coef(): entries outside these masks are identically zero
   RDC_HD static constexpr bool hasA(int a, int b) {
     return !((a == 0 && b == 4) || (a == 4 && b == 0) || (a == 1 && b == 4) || (a == 2 && b == 4));
@@ -137,7 +138,8 @@ struct Pihna {
   struct Pt {
     double n, c, h, v, a;
     double Tau, dT;            // crowding and its (common) derivative          :444-472
-    double Ve, Ve_dc, Ve_dv;   // vascular fraction; d/dh == d/dc               :474-499
+    double Ve, rV;             // vascular fraction and 1/(c+h+v) (0 in the clamped branches):
+                               // Ve__dc = Ve__dh = -Ve*rV, Ve__dv = (1-Ve)*rV    :474-499
     double Ua, Ua_da;          // cytokine uptake                               :501-502
   };
 
@@ -156,9 +158,9 @@ struct Pihna {
     const double chv = s.c + s.h + s.v;
     const double rchv = rcp(chv);
     const double Ve_ = s.v * rchv;  // NaN for chv == 0 drops into the last branch, as upstream
-    if (Ve_ <= 0.0) { s.Ve = 0.0; s.Ve_dc = 0.0; s.Ve_dv = 0.0; }
-    else if (Ve_ >= 1.0) { s.Ve = 1.0; s.Ve_dc = 0.0; s.Ve_dv = 0.0; }
-    else { s.Ve = Ve_; s.Ve_dc = -Ve_ * rchv; s.Ve_dv = (1.0 - Ve_) * rchv; }
+    if (Ve_ <= 0.0) { s.Ve = 0.0; s.rV = 0.0; }
+    else if (Ve_ >= 1.0) { s.Ve = 1.0; s.rV = 0.0; }
+    else { s.Ve = Ve_; s.rV = rchv; }
     const double raK = rcp(s.a + k.Ka);
     s.Ua = s.a * raK;
     s.Ua_da = raK - s.Ua * raK;
@@ -170,7 +172,8 @@ struct Pihna {
     o.zero();
     const double T = k.DT2;
     const double oneVe = 1.0 - s.Ve;
-    const double nVe_dc = -s.Ve_dc, nVe_dv = -s.Ve_dv;  // (-Ve__dc) etc. as written upstream
+    const double Ve_dc = -s.Ve * s.rV, Ve_dv = oneVe * s.rV;
+    const double nVe_dc = -Ve_dc, nVe_dv = -Ve_dv;  // (-Ve__dc) etc. as written upstream
     // thresholded transport coefficients, :504-509 (not stored in Pt: registers are scarcer than compares)
     const double dif_c = (s.c > k.Lambda ? k.dif_c : 0.0), tax_c = (s.c > k.Lambda ? k.tax_c : 0.0);
     const double dif_h = (s.h > k.Lambda ? k.dif_h : 0.0), tax_h = (s.h > k.Lambda ? k.tax_h : 0.0);
@@ -187,9 +190,9 @@ struct Pihna {
     o.RG[1][0] = -T * dif_c * s.Tau;
     o.RG[1][2] = -T * tax_c * s.Tau * s.c;
     o.A[1][0] = -T * (pc - k.nec_c * s.c);
-    o.A[1][1] = 1.0 - T * (k.prod_c * s.Tau + pc - k.c2h * oneVe - k.c2h * nVe_dc * s.c + k.h2c * s.Ve_dc * s.h - k.nec_c * s.n);
-    o.A[1][2] = -T * (pc - k.c2h * nVe_dc * s.c + k.h2c * s.Ve_dc * s.h + k.h2c * s.Ve);
-    o.A[1][3] = -T * (pc - k.c2h * nVe_dv * s.c + k.h2c * s.Ve_dv * s.h);
+    o.A[1][1] = 1.0 - T * (k.prod_c * s.Tau + pc - k.c2h * oneVe - k.c2h * nVe_dc * s.c + k.h2c * Ve_dc * s.h - k.nec_c * s.n);
+    o.A[1][2] = -T * (pc - k.c2h * nVe_dc * s.c + k.h2c * Ve_dc * s.h + k.h2c * s.Ve);
+    o.A[1][3] = -T * (pc - k.c2h * nVe_dv * s.c + k.h2c * Ve_dv * s.h);
     {
       const double bc = T * dif_c * s.dT, bv = T * tax_c * s.dT * s.c;
       for (int b = 0; b < 4; b++) { o.B[1][b][0] = bc; o.B[1][b][2] = bv; }
@@ -202,10 +205,10 @@ struct Pihna {
     o.RG[2][1] = -T * dif_h * s.Tau;
     o.RG[2][2] = -T * tax_h * s.Tau * s.h;
     o.A[2][0] = T * k.nec_h * s.h;
-    o.A[2][1] = -T * (k.c2h * oneVe + k.c2h * nVe_dc * s.c - k.h2c * s.Ve_dc * s.h - k.h2n * nVe_dc * s.h);
-    o.A[2][2] = 1.0 - T * (k.c2h * nVe_dc * s.c - k.h2c * s.Ve_dc * s.h - k.h2c * s.Ve - k.nec_h * s.n -
+    o.A[2][1] = -T * (k.c2h * oneVe + k.c2h * nVe_dc * s.c - k.h2c * Ve_dc * s.h - k.h2n * nVe_dc * s.h);
+    o.A[2][2] = 1.0 - T * (k.c2h * nVe_dc * s.c - k.h2c * Ve_dc * s.h - k.h2c * s.Ve - k.nec_h * s.n -
                            k.h2n * nVe_dc * s.h - k.h2n * oneVe);
-    o.A[2][3] = -T * (k.c2h * nVe_dv * s.c - k.h2c * s.Ve_dv * s.h - k.h2n * nVe_dv * s.h);
+    o.A[2][3] = -T * (k.c2h * nVe_dv * s.c - k.h2c * Ve_dv * s.h - k.h2n * nVe_dv * s.h);
     {
       const double bh = T * dif_h * s.dT, bv = T * tax_h * s.dT * s.h;
       for (int b = 0; b < 4; b++) { o.B[2][b][1] = bh; o.B[2][b][2] = bv; }
@@ -258,6 +261,7 @@ struct Ripf {
   using C = Coef<NV, NG>;
   // gradient field sources: >=0 index into u, <0 -> aux index (-1-k)
   RDC_HD static constexpr int grad_src(int k) { return k == 0 ? 2 : (k == 1 ? 0 : -3); }
+  RDC_HD static constexpr int row_order(int x) { return x; }
   RDC_HD static constexpr bool hasA(int a, int b) { return !((a == 1 && b == 0)); }
   RDC_HD static constexpr bool hasB(int a, int b, int) { return a == 2 && b >= 1; }
   RDC_HD static constexpr bool hasD(int a, int b) { return a == 2 && (b == 0 || b == 2); }
@@ -386,6 +390,7 @@ struct Hcc {
   using K = HccK;
   using C = Coef<NV, NG>;
   RDC_HD static constexpr int grad_src(int) { return 1; }
+  RDC_HD static constexpr int row_order(int x) { return x; }
   RDC_HD static constexpr bool hasA(int a, int b) { return !(a == 1 && b == 2); }
   RDC_HD static constexpr bool hasB(int a, int b, int) { return a == 1 && b <= 1; }
   RDC_HD static constexpr bool hasD(int a, int b) { return a == 1 && b == 1; }
