@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=119, help="K(n) mesh: n^3 cells x 6 tets (119 -> 10.1M tets)")
+    ap.add_argument("--mesh-n", dest="n", type=int, default=119, help="K(n) mesh: n^3 cells x 6 tets (119 -> 10.1M tets)")
     ap.add_argument("--params", default="shipped", choices=["shipped", "full", "realexp"])
     ap.add_argument("--scatter", default="auto", choices=["auto", "coloured", "rowgather"])
     ap.add_argument("--variant", default="auto", choices=["auto", "generic"])
