@@ -207,7 +207,7 @@ k_tet4_rg2(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
            const uint16_t* __restrict__ contrib, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int dbg) {
   constexpr int NV = M::NV, STRIDE = (4 * NV + 1) | 1, SLOT = NV + 1;  // odd stride: conflict-free ds_write_b64
-  __shared__ double stage[BLOCK * STRIDE];
+  __shared__ double stage[BLOCK * STRIDE + SLOT];  // + SLOT: the gather reads SLOT values from the last column too
   __shared__ double outbuf[BLOCK * SLOT];  // partial sums of one row pass: NV values + rhs per slot, nout <= BLOCK
   __shared__ uint2 clist2[BLOCK];          // 4 contribution entries (uint16) per pair
   __shared__ uint2 lchunk[BLOCK];

@@ -79,6 +79,21 @@ class Prep:
             if a.size:
                 lib.shim_prep_copy(idx, a.ctypes.data_as(C.c_void_p))
             setattr(self, name, a)
+        WG = np.dtype([("vb0", "<i8"), ("bb0", "<i8"), ("c0", "<i8"), ("ch0", "<i8"), ("n0", "<i4"), ("nnodes", "<i4"),
+                       ("nb", "<i4"), ("np", "<i4"), ("nch", "<i4"), ("nout", "<i4"), ("pad", "<i8")])
+        CH = np.dtype([("cbeg", "<u2"), ("cnt", "<u2"), ("dst", "<u2"), ("pad", "<u2")])
+        SD = np.dtype([("outoff", "<u2"), ("len", "u1"), ("nextra", "u1"), ("extra", "<u2"), ("diag", "u1"), ("node", "u1")])
+        for name, idx, dt in (("wg2", 12, WG), ("pair_rec", 13, np.uint32), ("pair_aux", 14, np.uint16),
+                              ("chunk", 15, CH), ("sdesc", 16, SD), ("contrib", 17, np.uint16)):
+            nbytes_or_count = lib.shim_prep_size(idx)
+            count = nbytes_or_count // np.dtype(dt).itemsize if idx in (12, 15, 16) else nbytes_or_count
+            a = np.empty(count, dtype=dt)
+            if a.size:
+                lib.shim_prep_copy(idx, a.ctypes.data_as(C.c_void_p))
+            setattr(self, name, a)
+        self.rg2_ok = bool(lib.shim_prep_size(103))
+        self.rg2_lds_bytes = lib.shim_prep_size(104)
+        self.rg2_block = lib.shim_prep_size(105)
         self.n_colours = lib.shim_prep_size(100)
         self.rowgather_ok = bool(lib.shim_prep_size(101))
         self.rg_lds_bytes = lib.shim_prep_size(102)

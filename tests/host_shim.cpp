@@ -148,9 +148,18 @@ int64_t shim_prep_size(int what) {
     case 9: return (int64_t)g_prep.pair_local.size();
     case 10: return (int64_t)g_prep.node_pair_ptr.size();
     case 11: return (int64_t)g_prep.wg_node_ptr.size();
+    case 12: return (int64_t)(g_prep.wg2.size() * sizeof(HostPrep::WgDesc));
+    case 13: return (int64_t)g_prep.pair_rec.size();
+    case 14: return (int64_t)g_prep.pair_aux.size();
+    case 15: return (int64_t)(g_prep.chunk.size() * sizeof(HostPrep::Chunk));
+    case 16: return (int64_t)(g_prep.sdesc.size() * sizeof(HostPrep::StoreDesc));
+    case 17: return (int64_t)g_prep.contrib.size();
     case 100: return g_prep.n_colours;
     case 101: return g_prep.rowgather_ok ? 1 : 0;
     case 102: return (int64_t)g_prep.rg_lds_bytes;
+    case 103: return g_prep.rg2_ok ? 1 : 0;
+    case 104: return (int64_t)g_prep.rg2_lds_bytes;
+    case 105: return g_prep.rg2_block;
   }
   return -1;
 }
@@ -169,6 +178,12 @@ int shim_prep_copy(int what, void* dst) {
     case 9: CP(pair_local);
     case 10: CP(node_pair_ptr);
     case 11: CP(wg_node_ptr);
+    case 12: CP(wg2);
+    case 13: CP(pair_rec);
+    case 14: CP(pair_aux);
+    case 15: CP(chunk);
+    case 16: CP(sdesc);
+    case 17: CP(contrib);
   }
 #undef CP
   return 1;

@@ -249,3 +249,73 @@ def test_timing_hook():
         ctx.assemble_pihna(p)
         ctx.synchronize()
         assert 0.0 < ctx.timing_last_ms() < 1e4
+
+
+# ---- two ranks (gloo, host-staged halo) sharing the one GPU of the test box ---------------------
+def _two_rank_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from rdcfes_amd import partition
+    from rdcfes_amd.halo import HaloExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        conn, xyz = synth.kuhn_tet_mesh(8, order="random")
+        u = synth.pihna_fields(xyz)
+        p = pihna_params_from_dict(synth.pihna_param_dict("full"))
+        part = partition.partition_rcb(xyz[conn].mean(axis=1), world)
+        lp = partition.build_local(conn, xyz, part, rank, world)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        u_l = torch.full((lp.node_global.size, 5), float("nan"), dtype=torch.float64, device=dev)
+        u_l[:lp.n_owned] = torch.from_numpy(u[lp.node_global[:lp.n_owned]]).to(dev)  # ghosts arrive by halo
+        hx = HaloExchange(lp, 5, dev)
+        with AssemblyContext(0) as ctx:
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.mesh_upload(4, lp.conn, lp.xyz, 5, n_owned=lp.n_owned)
+            ctx.field_bind_device(FIELD_OLD_SOLUTION, u_l.data_ptr(), u_l.numel())
+            hx.exchange(u_l)
+            ctx.assemble_pihna(p)
+            val, rhs = ctx.csr_download()
+            rp, col = ctx.csr_pattern()
+        # reference: the global assembly restricted to this rank's rows
+        grp, gcol, gval, grhs = O.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+        err = 0.0
+        for ln in range(0, lp.n_owned, 7):
+            g = lp.node_global[ln]
+            for a in range(5):
+                lr, gr = ln * 5 + a, g * 5 + a
+                lc = col[rp[lr]:rp[lr + 1]]
+                gc = lp.node_global[lc // 5] * 5 + lc % 5
+                order = np.argsort(gc)
+                assert np.array_equal(gc[order], gcol[grp[gr]:grp[gr + 1]])
+                ref = gval[grp[gr]:grp[gr + 1]]
+                err = max(err, np.abs(val[rp[lr]:rp[lr + 1]][order] - ref).max() / np.abs(gval).max())
+                err = max(err, abs(rhs[lr] - grhs[gr]) / np.abs(grhs).max())
+        dist.barrier()
+        q.put((rank, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partitioned_assembly():
+    """N > 1 path end to end on one GPU: RCB partition, ghost layer, halo exchange into a bound
+    device tensor, per-rank assembly of complete owned rows (no matrix exchange)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(err < TOL for _, err in res), res

@@ -101,6 +101,117 @@ def _replay_rowgather(P, conn, nen, nv, n_owned, rows_of):
     return val, rhs
 
 
+def _rot(nen, j, i):
+    return (j ^ i) if nen == 4 else (j + i) % nen
+
+
+def _pair_rows(P, conn, nen, rows_of, w, cache):
+    """(pair index -> (Ke, Fe, element, local row index)) for the flat work lists of workgroup w"""
+    d = P.wg2[w]
+    B = P.rg2_block
+    out = []
+    for idx in range(d["np"]):
+        nodes = P.pair_rec[(w * B + idx) * nen:(w * B + idx + 1) * nen]
+        # recover (element, i) from the pair record: the row node is first, the others rotated
+        I = int(nodes[0])
+        cand = [(e, i) for e in np.nonzero((conn == I).any(axis=1))[0] for i in range(nen)
+                if conn[e, i] == I and all(conn[e, _rot(nen, j, i)] == nodes[j] for j in range(nen))]
+        assert len(cand) >= 1
+        e, i = cand[0]
+        if e not in cache:
+            cache[e] = rows_of(e)
+        out.append((cache[e][0], cache[e][1], e, i))
+    assert np.all(P.pair_rec[(w * B + d["np"]) * nen:(w + 1) * B * nen] == 0xFFFFFFFF)
+    return out
+
+
+def _replay_flat_lds(P, conn, nen, nv, n_owned, rows_of):
+    """k_tet4_rg3: LDS slice addressed through pair_aux"""
+    val = np.full(nv * nv * P.bptr[n_owned], np.nan)
+    rhs = np.full(n_owned * nv, np.nan)
+    cache = {}
+    B = P.rg2_block
+    for w, d in enumerate(P.wg2):
+        nval, nrhs = d["nb"] * nv * nv, d["nnodes"] * nv
+        assert 8 * (nval + nrhs) <= P.rg2_lds_bytes
+        lds = np.zeros(nval + nrhs)
+        for idx, (Ke, Fe, e, i) in enumerate(_pair_rows(P, conn, nen, rows_of, w, cache)):
+            ax = P.pair_aux[(w * B + idx) * 8:(w * B + idx + 1) * 8]
+            rowoff, stride, rhsoff, off = int(ax[0]), int(ax[1]), int(ax[2]), ax[4:8].astype(int)
+            for a in range(nv):
+                lds[nval + rhsoff + a] += Fe[a * nen + i]
+                for j in range(nen):
+                    jo = _rot(nen, j, i)
+                    for b in range(nv):
+                        lds[rowoff + a * stride + off[j] + b] += Ke[a * nen + i, b * nen + jo]
+        val[d["vb0"]:d["vb0"] + nval] = lds[:nval]
+        rhs[d["n0"] * nv:(d["n0"] + d["nnodes"]) * nv] = lds[nval:]
+    return val, rhs
+
+
+def _replay_staged(P, conn, nen, nv, n_owned, rows_of):
+    """k_tet4_rg2: per-row stage buffer, chunked gather in fixed order, store descriptors"""
+    val = np.full(nv * nv * P.bptr[n_owned], np.nan)
+    rhs = np.full(n_owned * nv, np.nan)
+    cache = {}
+    stride = (nen * nv + 1) | 1
+    slot = nv + 1
+    for w, d in enumerate(P.wg2):
+        pairs = _pair_rows(P, conn, nen, rows_of, w, cache)
+        chunks = P.chunk[d["ch0"]:d["ch0"] + d["nch"]]
+        sds = P.sdesc[d["bb0"]:d["bb0"] + d["nb"]]
+        clist = P.contrib[d["c0"]:d["c0"] + d["np"] * nen]
+        assert d["nout"] <= P.rg2_block and d["nch"] <= P.rg2_block and chunks["cnt"].max() <= 6
+        for a in range(nv):
+            stage = np.full(P.rg2_block * stride, np.nan)
+            for idx, (Ke, Fe, e, i) in enumerate(pairs):
+                for j in range(nen):
+                    jo = _rot(nen, j, i)
+                    for b in range(nv):
+                        stage[idx * stride + (b if j == 0 else j * nv + 1 + b)] = Ke[a * nen + i, b * nen + jo]
+                stage[idx * stride + nv] = Fe[a * nen + i]
+            outbuf = np.full(P.rg2_block * slot, np.nan)
+            for ch in chunks:
+                acc = np.zeros(slot)
+                for x in range(ch["cnt"]):
+                    src = int(clist[ch["cbeg"] + x])
+                    acc += stage[src:src + slot]
+                outbuf[ch["dst"] * slot:(ch["dst"] + 1) * slot] = acc
+            for ob, sd in enumerate(sds):
+                outoff, ln, nextra, extra = int(sd["outoff"]), int(sd["len"]), int(sd["nextra"]), int(sd["extra"])
+                for b in range(nv):
+                    v = outbuf[ob * slot + b] + sum(outbuf[(extra + x) * slot + b] for x in range(nextra))
+                    val[int(d["vb0"]) + outoff + a * nv * ln + b] = v
+                if sd["diag"]:
+                    r = outbuf[ob * slot + nv] + sum(outbuf[(extra + x) * slot + nv] for x in range(nextra))
+                    rhs[(int(d["n0"]) + int(sd["node"])) * nv + a] = r
+    return val, rhs
+
+
+@pytest.mark.parametrize("owned_frac", [1.0, 0.6])
+def test_flat_work_lists_replay_matches_oracle(oracle, shim, make_prep, owned_frac):
+    """the work lists of the default TET4 kernels (k_tet4_rg3 / k_tet4_rg2), replayed in numpy"""
+    conn, xyz = _mesh(4, 3)
+    n_node = xyz.shape[0]
+    n_owned = int(round(owned_frac * n_node))
+    if n_owned < n_node:
+        conn = conn[(conn < n_owned).any(axis=1)]
+    p = pihna_params_from_dict(synth.pihna_param_dict("full"))
+    u = synth.pihna_fields(xyz)
+    P = make_prep(4, conn, n_node, n_owned, 5, lds_budget=24 * 1024)
+    assert P.ok and P.rg2_ok
+    rows_of = lambda e: shim_rows(shim, 0, 4, p, xyz[conn[e]], u[conn[e]], fast=True)
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u, n_owned=n_owned)
+    for replay in (_replay_flat_lds, _replay_staged):
+        val, rhs = replay(P, conn, 4, 5, n_owned, rows_of)
+        assert not np.isnan(val).any() and not np.isnan(rhs).any(), "some CSR entry was never written"
+        np.testing.assert_allclose(rhs, rhs0, rtol=1e-10, atol=1e-12 * np.abs(rhs0).max())
+        np.testing.assert_allclose(val, val0, rtol=1e-10, atol=1e-12 * np.abs(val0).max())
+    # node ranges of the workgroups tile the owned nodes
+    assert P.wg2["n0"][0] == 0 and np.all(P.wg2["n0"][1:] == (P.wg2["n0"] + P.wg2["nnodes"])[:-1])
+    assert P.wg2["n0"][-1] + P.wg2["nnodes"][-1] == n_owned
+
+
 @pytest.mark.parametrize("nen,model", [(4, 0), (8, 2)])
 @pytest.mark.parametrize("owned_frac", [1.0, 0.6])
 def test_scatter_replay_matches_oracle(oracle, shim, make_prep, nen, model, owned_frac):
