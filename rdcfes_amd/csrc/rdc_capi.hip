@@ -36,7 +36,7 @@ struct rdc_ctx {
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
       wg_node_ptr;
   DevBuf val, rhs, packed;
-  DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux;
+  DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab;
   DevBuf field[RDC_FIELD_COUNT];
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
   // solid
@@ -194,6 +194,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.sdesc = (const HostPrep::StoreDesc*)c->rg2_sdesc.p;
     a.rg2.contrib = (const uint16_t*)c->rg2_contrib.p;
     a.rg2.pair_aux = (const uint16_t*)c->rg2_aux.p;
+    a.rg2.node_tab = (const uint16_t*)c->rg2_ntab.p;
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
   }
   a.val = (double*)c->val.p;
@@ -253,7 +254,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
-                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux,
+                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
@@ -316,7 +317,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   if (rc) return rc;
   c->have_mesh = false;
   // LDS budget of a row-gather workgroup: half the per-block limit keeps two workgroups per CU
-  const size_t budget = c->max_lds >= 64 * 1024 ? 36 * 1024 : c->max_lds / 2;
+  const size_t budget = c->max_lds >= 64 * 1024 ? 50 * 1024 : c->max_lds / 2;
   std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, 256, c->prep);
   if (!err.empty()) return fail(c, RDC_ERR_INVALID, "%s", err.c_str());
   const HostPrep& P = c->prep;
@@ -340,6 +341,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
     if ((rc = dev_upload(c, c->rg2_sdesc, P.sdesc))) return rc;
     if ((rc = dev_upload(c, c->rg2_contrib, P.contrib))) return rc;
     if ((rc = dev_upload(c, c->rg2_aux, P.pair_aux))) return rc;
+    if ((rc = dev_upload(c, c->rg2_ntab, P.node_tab))) return rc;
   }
   const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
   if ((rc = dev_alloc(c, c->val, nnz * sizeof(double)))) return rc;

@@ -22,6 +22,7 @@ struct Rg2Dev {
   const HostPrep::StoreDesc* sdesc = nullptr;
   const uint16_t* contrib = nullptr;
   const uint16_t* pair_aux = nullptr;
+  const uint16_t* node_tab = nullptr;
   size_t lds_bytes = 0;
 };
 

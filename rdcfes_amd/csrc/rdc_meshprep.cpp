@@ -216,14 +216,17 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
     for (int64_t n = 0; n < n_owned && P.rg2_ok; n++) {
       const int64_t np = inc_ptr[n + 1] - inc_ptr[n];
       const int64_t len = P.bptr[n + 1] - P.bptr[n];
-      const size_t nbytes = sizeof(double) * ((size_t)nvar * nvar * len + nvar);
-      if (nbytes > lds_budget_bytes) { P.rg2_ok = false; break; }
+      // row slice of the node; the private diagonal accumulators are a fixed-size area
+      const size_t diag_area = sizeof(double) * (size_t)HostPrep::RG3_DIAG_SLOTS * (nvar * nvar + nvar);
+      const size_t nbytes = sizeof(double) * ((size_t)nvar * nvar * len);
+      if (nbytes + diag_area > lds_budget_bytes) { P.rg2_ok = false; break; }
       int64_t nch = 0;
       for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) nch += std::max<int64_t>(1, (bcnt[b] + CH - 1) / CH);
       if (np > block || nch + 1 > block || len > 255) { P.rg2_ok = false; break; }
       // gather work items of a workgroup: its chunks plus one rhs item per node
       if (n > wgp.back() && (pairs + np > block || chunks + nch + (n - wgp.back() + 1) > block || n - wgp.back() >= 255 ||
-                             bytes + nbytes > lds_budget_bytes)) {
+                             n - wgp.back() >= HostPrep::RG3_DIAG_SLOTS / HostPrep::RG3_DIAG_COPIES ||
+                             bytes + nbytes + diag_area > lds_budget_bytes)) {
         wgp.push_back(n);
         pairs = 0;
         chunks = 0;
@@ -232,7 +235,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
       pairs += np;
       chunks += nch;
       bytes += nbytes;
-      max_bytes = std::max(max_bytes, bytes);
+      max_bytes = std::max(max_bytes, bytes + diag_area);
     }
     P.rg2_lds_bytes = max_bytes;
     wgp.push_back(n_owned);
@@ -244,6 +247,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
       P.wg2.resize((size_t)nwg);
       P.pair_rec.assign((size_t)nwg * block * nen, 0xFFFFFFFFu);
       if (nen == 4) P.pair_aux.assign((size_t)nwg * block * 8, 0);
+      P.node_tab.assign((size_t)n_owned * 4, 0);
       P.sdesc.resize((size_t)P.bptr[n_owned]);
       P.contrib.assign((size_t)inc_ptr[n_owned] * nen + (size_t)block * nen, 0);  // tail pad: vector loads may overrun
       // chunk offsets per workgroup
@@ -274,6 +278,15 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         int extra = d.nb;  // partial-sum slots: [0, nb) one per block, then the extra chunks
         for (int64_t n = n0; n < n1; n++) {
           const int64_t len = P.bptr[n + 1] - P.bptr[n];
+          {
+            const int32_t* bc = P.bcol.data() + P.bptr[n];
+            const int64_t dslot = std::lower_bound(bc, bc + len, (int32_t)n) - bc;
+            uint16_t* nt = &P.node_tab[(size_t)n * 4];
+            nt[0] = (uint16_t)((int64_t)nvar * nvar * (P.bptr[n] - d.bb0));
+            nt[1] = (uint16_t)(nvar * len);
+            nt[2] = (uint16_t)(nvar * dslot);
+            nt[3] = 0;
+          }
           for (int64_t s2 = 0; s2 < len; s2++) {
             const int64_t gb = P.bptr[n] + s2;
             const int lb = (int)(gb - d.bb0);
@@ -327,7 +340,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
       }
       if (fail_flag) P.rg2_ok = false;
     }
-    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); }
+    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); }
   }
   return std::string();
 }

@@ -66,7 +66,10 @@ struct HostPrep {
   // per pair, for the LDS-accumulating kernel: offsets inside the workgroup's row slice (doubles):
   // {rowoff, stride = nvar*len, rhsoff, pad, off[0..3] = nvar*slot of rotated column j}  (TET4 only)
   std::vector<uint16_t> pair_aux;   // [n_wg][block][8]
-  size_t rg2_lds_bytes = 0;         // largest row slice (values + rhs) of a workgroup
+  size_t rg2_lds_bytes = 0;         // largest row slice (values + rhs + private diagonal copies) of a workgroup
+  static constexpr int RG3_DIAG_COPIES = 6;  // private accumulators of a node's diagonal block + rhs
+  static constexpr int RG3_DIAG_SLOTS = 64;  // fixed slot count (node * COPIES + copy) => at most 10 nodes per workgroup
+  std::vector<uint16_t> node_tab;   // [n_owned][4] {rowoff, stride, nvar*diag slot, 0}: where the diagonal block sits
   std::vector<Chunk> chunk;
   std::vector<StoreDesc> sdesc;     // [total node blocks]
   std::vector<uint16_t> contrib;    // stage index (doubles) of the contribution: pair * stride + slot(column), see rdc_meshprep.cpp

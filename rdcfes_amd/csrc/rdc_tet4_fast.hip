@@ -143,12 +143,35 @@ k_tet4_rowgather(const MeshDev m, const typename M::K k, const double* __restric
 // descriptor and one 32-byte pair record that are addressed by blockIdx / threadIdx alone, so the
 // dependent load chain is two levels deep (descriptor | pair record -> node records) instead of
 // five (wg_node_ptr -> bptr / node_pair_ptr -> pair_elem -> conn / eslot -> records, bptr[I]).
+// LDS sink of k_tet4_rg3.  Off-diagonal blocks: atomic adds into the row slice.  The diagonal
+// block and the rhs of a node receive one contribution from EVERY pair of the node, i.e. the ~6
+// lanes of a wave that share the node would hit the same address -- measured at 51 CU-cycles per
+// wave-instruction against 6.3 for distinct consecutive addresses (tools/lds_atomic_bench.hip).
+// They therefore go to private accumulators laid out [value][node * COPIES + copy]: within one
+// wave-instruction every lane has its own (consecutive) address.
+template <class M>
+struct LdsSink3 {
+  double* row;     // row slice of the owner node
+  double* dacc;    // private diagonal accumulators of this lane: dacc[v * NS], NS a compile-time constant
+  static constexpr int ns = HostPrep::RG3_DIAG_SLOTS;
+  int stride;      // NV * len
+  int off[4];      // NV * slot of rotated column j (off[0] unused)
+  __device__ __forceinline__ void ke(int a, int b, int j, double v) {
+    if (!block_nonzero<M>(a, b)) return;  // accumulators are pre-zeroed
+    double* p = (j == 0) ? dacc + (a * M::NV + b) * ns : row + a * stride + off[j] + b;
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void fe(int a, double v) {
+    __hip_atomic_fetch_add(dacc + (M::NV * M::NV + a) * ns, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+};
+
 template <class M, int EXP_MODE, int BLOCK, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW)
 k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_rec,
-           const uint16_t* __restrict__ pair_aux, const typename M::K k, const double* __restrict__ rec,
-           double* __restrict__ val, double* __restrict__ rhs) {
-  constexpr int NV = M::NV, NW = BLOCK / 64;
+           const uint16_t* __restrict__ pair_aux, const uint16_t* __restrict__ node_tab, const typename M::K k,
+           const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs) {
+  constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::RG3_DIAG_COPIES, NDV = NV * NV + NV;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int w = blockIdx.x;
   // lane l of wave v takes pair l*NW + v (spreads the pairs of one node over the waves)
@@ -164,25 +187,40 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     load_rec<M>(rec, pr.z, X[2], U[2], AX[2]);
     load_rec<M>(rec, pr.w, X[3], U[3], AX[3]);
   }
-  // zero the row slice while the loads are in flight
-  const int nval = d.nb * NV * NV, nrhs = d.nnodes * NV;
-  for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
+  // zero the accumulators while the loads are in flight: [row slice | private diagonals]
+  constexpr int ns = HostPrep::RG3_DIAG_SLOTS;
+  const int nval = d.nb * NV * NV, ntot = nval + NDV * ns;
+  for (int x = threadIdx.x; x < ntot; x += BLOCK) lds[x] = 0.0;
   __syncthreads();
   if (valid) {
-    LdsSink<M, 0> sink;
-    sink.dummy = 0.0;
+    LdsSink3<M> sink;
     sink.row = lds + (ax.x & 0xFFFF);
     sink.stride = (int)(ax.x >> 16);
-    sink.lrhs = lds + nval + (ax.y & 0xFFFF);
-    sink.off[0] = (int)(ax.z & 0xFFFF); sink.off[1] = (int)(ax.z >> 16);
+    // the pairs of a node that share a wave have consecutive idx / NW: distinct copies (mod NC)
+    sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (idx / NW) % NC;
+    sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
     sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
     tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
   }
   __syncthreads();
+  // fold the private copies: diagonal block values into the row slice, rhs straight to memory
+  for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
+    const int n = x / NDV, v = x - n * NDV;
+    const double* src = lds + nval + v * ns + n * NC;
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) sum += src[c];
+    if (v < NV * NV) {
+      const uint2 nt = reinterpret_cast<const uint2*>(node_tab)[d.n0 + n];  // {rowoff | stride << 16, diagoff}
+      const int a = v / NV, b = v - a * NV;
+      lds[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + b] = sum;  // nothing else writes the diagonal
+    } else {
+      rhs[(int64_t)(d.n0 + n) * NV + (v - NV * NV)] = sum;
+    }
+  }
+  __syncthreads();
   double* out = val + d.vb0;
   for (int x = threadIdx.x; x < nval; x += BLOCK) __builtin_nontemporal_store(lds[x], out + x);
-  double* orhs = rhs + (int64_t)d.n0 * NV;
-  for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lds[nval + x];
 }
 
 // ---- staged row gather (the default TET4 path) ----------------------------------------------
@@ -346,7 +384,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     constexpr int BLOCK = 256;
 #define RDC_RG3(MINW)                                                                                              \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
-                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, k, a.packed, a.val, a.rhs)
+                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs)
     if (a.opt_occ == 1) RDC_RG3(1);
     else if (a.opt_occ == 3) RDC_RG3(3);
     else RDC_RG3(2);
