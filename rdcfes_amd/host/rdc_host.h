@@ -1,0 +1,364 @@
+// rdc_host.h — C++ host layer above the C-ABI (include/rdc_assembly.h) that mirrors the slice of the
+// libMesh interface the reference's assemble callbacks live in, so that the drop-in replacements
+// keep the reference's names, argument meaning and call order:
+//
+//     model.attach_assemble_function(assemble_pihna);     // src/pihna.C:35
+//     model.solve();                                      // src/pihna.C:80  -> assemble() -> callback
+//     void assemble_pihna(EquationSystems& es, const std::string& system_name);   // src/pihna.C:318
+//
+// libMesh itself is not available in this build environment (README.md:35 pins d3bda6c), so this is
+// NOT libMesh: it is the minimal set of types with the same member names that the callbacks and the
+// time loop touch (EquationSystems::parameters / get_system / get_mesh, System::n_vars,
+// TransientLinearImplicitSystem::{old_local_solution, matrix, rhs, attach_assemble_function}).
+// A libMesh build uses integration/libmesh_adapter.C instead, which binds the same C-ABI calls to
+// the real libMesh objects.
+//
+// Header-only, C++17, depends only on the C-ABI.  Errors: the reference aborts through
+// libmesh_error(); here every failing C-ABI status becomes a std::runtime_error carrying
+// rdc_last_error().
+#ifndef RDC_HOST_H
+#define RDC_HOST_H
+
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+#include "../../include/rdc_assembly.h"
+
+namespace rdc {
+namespace host {
+
+using Real = double;
+using Number = double;
+using dof_id_type = uint32_t;
+
+inline void check(rdc_ctx* c, int rc, const char* what) {
+  if (rc != RDC_OK) throw std::runtime_error(std::string(what) + ": " + rdc_last_error(c));
+}
+
+// ---- libMesh::Parameters (string-keyed, typed) ------------------------------------------------
+class Parameters {
+ public:
+  template <class T> T& set(const std::string& key) {
+    auto& v = map_[key];
+    if (!std::holds_alternative<T>(v)) v = T();
+    return std::get<T>(v);
+  }
+  template <class T> const T& get(const std::string& key) const {
+    auto it = map_.find(key);
+    if (it == map_.end()) throw std::runtime_error("Parameters::get: no parameter '" + key + "'");
+    if (!std::holds_alternative<T>(it->second)) throw std::runtime_error("Parameters::get: type mismatch for '" + key + "'");
+    return std::get<T>(it->second);
+  }
+  template <class T> bool have_parameter(const std::string& key) const {
+    auto it = map_.find(key);
+    return it != map_.end() && std::holds_alternative<T>(it->second);
+  }
+ private:
+  std::map<std::string, std::variant<Real, int, bool, std::string>> map_;
+};
+
+// ---- mesh: FIRST-order TET4 / HEX8, libMesh node order -----------------------------------------
+class Mesh {
+ public:
+  Mesh(int elem_type, std::vector<uint32_t> conn, std::vector<double> xyz)
+      : elem_type_(elem_type), conn_(std::move(conn)), xyz_(std::move(xyz)) {
+    if (elem_type != RDC_TET4 && elem_type != RDC_HEX8) throw std::runtime_error("Mesh: TET4 or HEX8 only");
+    if (conn_.size() % elem_type || xyz_.size() % 3) throw std::runtime_error("Mesh: ragged arrays");
+  }
+  unsigned int mesh_dimension() const { return 3; }
+  int64_t n_elem() const { return (int64_t)conn_.size() / elem_type_; }
+  int64_t n_nodes() const { return (int64_t)xyz_.size() / 3; }
+  int elem_type() const { return elem_type_; }
+  const std::vector<uint32_t>& connectivity() const { return conn_; }
+  std::vector<double>& coordinates() { return xyz_; }              // moving mesh (SolidSystem::update)
+  const std::vector<double>& coordinates() const { return xyz_; }
+ private:
+  int elem_type_;
+  std::vector<uint32_t> conn_;
+  std::vector<double> xyz_;
+};
+
+// ---- NumericVector / SparseMatrix (host copies; the GPU owns the assembled values) --------------
+class NumericVector {
+ public:
+  void init(int64_t n) { v_.assign((size_t)n, 0.0); }
+  int64_t size() const { return (int64_t)v_.size(); }
+  Number operator()(int64_t i) const { return v_[(size_t)i]; }
+  void set(int64_t i, Number x) { v_[(size_t)i] = x; }
+  void zero() { std::fill(v_.begin(), v_.end(), 0.0); }
+  Real l2_norm() const { long double s = 0; for (double x : v_) s += (long double)x * x; return (Real)std::sqrt((double)s); }
+  NumericVector& operator=(const NumericVector&) = default;
+  std::vector<double>& raw() { return v_; }
+  const std::vector<double>& raw() const { return v_; }
+ private:
+  std::vector<double> v_;
+};
+
+class SparseMatrix {  // scalar CSR == PETSc AIJ, row = node*nvar + var
+ public:
+  std::vector<int64_t> row_ptr;
+  std::vector<int32_t> col_idx;
+  std::vector<double> val;
+  int64_t m() const { return (int64_t)row_ptr.size() - 1; }
+  void zero() { std::fill(val.begin(), val.end(), 0.0); }
+  Number operator()(int64_t i, int64_t j) const {
+    for (int64_t k = row_ptr[(size_t)i]; k < row_ptr[(size_t)i + 1]; k++) if (col_idx[(size_t)k] == j) return val[(size_t)k];
+    return 0.0;
+  }
+  void vector_mult(std::vector<double>& y, const std::vector<double>& x) const {
+    y.assign((size_t)m(), 0.0);
+    for (int64_t i = 0; i < m(); i++) {
+      double s = 0.0;
+      for (int64_t k = row_ptr[(size_t)i]; k < row_ptr[(size_t)i + 1]; k++) s += val[(size_t)k] * x[(size_t)col_idx[(size_t)k]];
+      y[(size_t)i] = s;
+    }
+  }
+};
+
+class EquationSystems;
+
+// ---- System / TransientLinearImplicitSystem -----------------------------------------------------
+class System {
+ public:
+  System(EquationSystems& es, std::string name) : es_(es), name_(std::move(name)) {}
+  virtual ~System() = default;
+  const std::string& name() const { return name_; }
+  unsigned int add_variable(const std::string& var) { vars_.push_back(var); return (unsigned)vars_.size() - 1; }
+  unsigned int n_vars() const { return (unsigned)vars_.size(); }
+  EquationSystems& get_equation_systems() { return es_; }
+  // dof = node * n_vars + var (libMesh variable-group numbering)
+  NumericVector solution, current_local_solution;
+  Number current_solution(dof_id_type dof) const { return current_local_solution((int64_t)dof); }
+  virtual void init(int64_t n_nodes) {
+    solution.init(n_nodes * n_vars());
+    current_local_solution.init(n_nodes * n_vars());
+  }
+  void update() { current_local_solution = solution; }  // serial: ghost update is the identity
+ protected:
+  EquationSystems& es_;
+  std::string name_;
+  std::vector<std::string> vars_;
+};
+
+class TransientLinearImplicitSystem : public System {
+ public:
+  using AssembleFn = void (*)(EquationSystems&, const std::string&);
+  using System::System;
+  NumericVector old_local_solution, older_local_solution, rhs_storage;
+  SparseMatrix matrix_storage;
+  NumericVector* rhs = &rhs_storage;
+  SparseMatrix* matrix = &matrix_storage;
+  Real time = 0.0;
+  void attach_assemble_function(AssembleFn f) { assemble_fn_ = f; }
+  Number old_solution(dof_id_type dof) const { return old_local_solution((int64_t)dof); }
+  SparseMatrix& get_system_matrix() { return matrix_storage; }
+  void init(int64_t n_nodes) override {
+    System::init(n_nodes);
+    old_local_solution.init(n_nodes * n_vars());
+    older_local_solution.init(n_nodes * n_vars());
+    rhs_storage.init(n_nodes * n_vars());
+  }
+  // ImplicitSystem::assemble(): zero matrix and rhs, then System::user_assembly() -> the callback
+  void assemble() {
+    if (!assemble_fn_) throw std::runtime_error("no assemble function attached to system " + name_);
+    matrix_storage.zero();
+    rhs_storage.zero();
+    assemble_fn_(es_, name_);
+  }
+  // LinearImplicitSystem::solve(): assemble, linear solve (stand-in: the reference hands the system
+  // to PETSc KSP, which stays on the host and is out of this project's scope), update()
+  int solve(Real tol = 1e-12, int max_its = 5000);
+ private:
+  AssembleFn assemble_fn_ = nullptr;
+};
+
+// ---- EquationSystems ----------------------------------------------------------------------------
+class EquationSystems {
+ public:
+  explicit EquationSystems(Mesh& mesh, int device = 0) : mesh_(mesh), device_(device) {}
+  ~EquationSystems() { for (auto& kv : ctx_) rdc_ctx_destroy(kv.second); }
+  EquationSystems(const EquationSystems&) = delete;
+  Parameters parameters;
+  Mesh& get_mesh() { return mesh_; }
+  template <class T> T& add_system(const std::string& name) {
+    auto p = std::make_unique<T>(*this, name);
+    T& ref = *p;
+    systems_[name] = std::move(p);
+    return ref;
+  }
+  template <class T> T& get_system(const std::string& name) {
+    auto it = systems_.find(name);
+    if (it == systems_.end()) throw std::runtime_error("EquationSystems::get_system: no system '" + name + "'");
+    T* p = dynamic_cast<T*>(it->second.get());
+    if (!p) throw std::runtime_error("EquationSystems::get_system: wrong type for '" + name + "'");
+    return *p;
+  }
+  bool has_system(const std::string& name) const { return systems_.count(name) != 0; }
+  // es.init(): DoF numbering, sparsity pattern, vector allocation (src/pihna.C:48)
+  void init() {
+    for (auto& kv : systems_) {
+      kv.second->init(mesh_.n_nodes());
+      if (auto* t = dynamic_cast<TransientLinearImplicitSystem*>(kv.second.get())) {
+        rdc_ctx* c = context(t->name(), (int)t->n_vars());
+        int64_t n_rows = 0, nnz = 0;
+        check(c, rdc_csr_dims(c, &n_rows, &nnz), "rdc_csr_dims");
+        t->matrix_storage.row_ptr.resize((size_t)n_rows + 1);
+        t->matrix_storage.col_idx.resize((size_t)nnz);
+        t->matrix_storage.val.assign((size_t)nnz, 0.0);
+        check(c, rdc_csr_pattern_download(c, t->matrix_storage.row_ptr.data(), t->matrix_storage.col_idx.data()), "pattern");
+      }
+    }
+  }
+  // one assembly context (GPU-resident mesh + pattern) per implicit system
+  rdc_ctx* context(const std::string& system, int nvar) {
+    auto it = ctx_.find(system);
+    if (it != ctx_.end()) return it->second;
+    rdc_ctx* c = nullptr;
+    int rc = rdc_ctx_create(device_, &c);
+    if (rc != RDC_OK) throw std::runtime_error(std::string("rdc_ctx_create: ") + rdc_last_error(nullptr));
+    ctx_[system] = c;
+    check(c, rdc_mesh_upload(c, mesh_.elem_type(), mesh_.n_elem(), mesh_.n_nodes(), mesh_.n_nodes(),
+                             mesh_.connectivity().data(), mesh_.coordinates().data(), nvar), "rdc_mesh_upload");
+    return c;
+  }
+ private:
+  Mesh& mesh_;
+  int device_;
+  std::map<std::string, std::unique_ptr<System>> systems_;
+  std::map<std::string, rdc_ctx*> ctx_;
+};
+
+// BiCGStab with Jacobi preconditioning: a stand-in for "linear_solver->solve(matrix, solution, rhs)".
+inline int TransientLinearImplicitSystem::solve(Real tol, int max_its) {
+  assemble();
+  const SparseMatrix& A = matrix_storage;
+  const std::vector<double>& b = rhs_storage.raw();
+  std::vector<double>& x = solution.raw();
+  const size_t n = b.size();
+  std::vector<double> dinv(n, 1.0), r(n), r0(n), p(n, 0.0), v(n, 0.0), s(n), t(n), y(n), z(n), tmp;
+  for (size_t i = 0; i < n; i++) { const double d = A((int64_t)i, (int64_t)i); if (d != 0.0) dinv[i] = 1.0 / d; }
+  A.vector_mult(tmp, x);
+  double bn = 0.0;
+  for (size_t i = 0; i < n; i++) { r[i] = b[i] - tmp[i]; r0[i] = r[i]; bn += b[i] * b[i]; }
+  bn = std::sqrt(bn) > 0 ? std::sqrt(bn) : 1.0;
+  double rho = 1, alpha = 1, omega = 1;
+  int it = 0;
+  for (; it < max_its; it++) {
+    double rn = 0, rho1 = 0;
+    for (size_t i = 0; i < n; i++) { rn += r[i] * r[i]; rho1 += r0[i] * r[i]; }
+    if (std::sqrt(rn) <= tol * bn) break;
+    const double beta = (rho1 / rho) * (alpha / omega);
+    rho = rho1;
+    for (size_t i = 0; i < n; i++) { p[i] = r[i] + beta * (p[i] - omega * v[i]); y[i] = dinv[i] * p[i]; }
+    A.vector_mult(v, y);
+    double r0v = 0;
+    for (size_t i = 0; i < n; i++) r0v += r0[i] * v[i];
+    alpha = rho / r0v;
+    for (size_t i = 0; i < n; i++) { s[i] = r[i] - alpha * v[i]; z[i] = dinv[i] * s[i]; }
+    A.vector_mult(t, z);
+    double ts = 0, tt = 0;
+    for (size_t i = 0; i < n; i++) { ts += t[i] * s[i]; tt += t[i] * t[i]; }
+    omega = tt > 0 ? ts / tt : 0.0;
+    for (size_t i = 0; i < n; i++) { x[i] += alpha * y[i] + omega * z[i]; r[i] = s[i] - omega * t[i]; }
+  }
+  update();
+  return it;
+}
+
+// ---- the drop-in callbacks: same signature as the reference's static assemble_* -----------------
+namespace detail {
+inline void pull_results(rdc_ctx* c, TransientLinearImplicitSystem& sys) {
+  check(c, rdc_csr_download(c, sys.matrix_storage.val.data(), sys.rhs_storage.raw().data()), "rdc_csr_download");
+}
+inline Real getR(const Parameters& p, const char* k) { return p.get<Real>(k); }
+}  // namespace detail
+
+// src/pihna.C:318-758
+inline void assemble_pihna(EquationSystems& es, const std::string& system_name) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  if (system.n_vars() != 5) throw std::runtime_error("assemble_pihna: system must have 5 variables (n,c,h,v,a)");
+  const Parameters& P = es.parameters;
+  rdc_pihna_params p;
+  p.time_step = detail::getR(P, "time_step");
+  p.cells_min_capacity = detail::getR(P, "cells_min_capacity");
+  p.cells_max_capacity = detail::getR(P, "cells_max_capacity");
+  p.cytokines_max_capacity = detail::getR(P, "cytokines_max_capacity");
+  p.cells_max_capacity_exponent = detail::getR(P, "cells_max_capacity/exponent");
+  p.necrosis_c = detail::getR(P, "necrosis/c"); p.necrosis_h = detail::getR(P, "necrosis/h"); p.necrosis_v = detail::getR(P, "necrosis/v");
+  p.diffuse_c = detail::getR(P, "diffuse/c"); p.taxis_c = detail::getR(P, "taxis/c");
+  p.diffuse_h = detail::getR(P, "diffuse/h"); p.taxis_h = detail::getR(P, "taxis/h");
+  p.produce_c = detail::getR(P, "produce/c");
+  p.switch_c2h = detail::getR(P, "switch/c/to/h"); p.switch_h2c = detail::getR(P, "switch/h/to/c"); p.switch_h2n = detail::getR(P, "switch/h/to/n");
+  p.diffuse_v = detail::getR(P, "diffuse/v"); p.taxis_v = detail::getR(P, "taxis/v"); p.produce_v = detail::getR(P, "produce/v");
+  p.secrete_a_c = detail::getR(P, "secrete/a/from/c"); p.secrete_a_h = detail::getR(P, "secrete/a/from/h");
+  p.uptake_a_v = detail::getR(P, "uptake/a/from/v"); p.decay_a = detail::getR(P, "decay/a");
+  rdc_ctx* c = es.context(system_name, 5);
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.old_local_solution.raw().data(), system.old_local_solution.size()), "old solution");
+  check(c, rdc_assemble_pihna(c, &p), "rdc_assemble_pihna");
+  detail::pull_results(c, system);
+}
+
+// src/ripf.C:337-673: reads the "RIPF-TimeDeriv" (vars 1,2) and "RT" (var 2) systems too
+inline void assemble_ripf(EquationSystems& es, const std::string& system_name) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  if (system.n_vars() != 3) throw std::runtime_error("assemble_ripf: system must have 3 variables (HU,cc,fb)");
+  System& TD = es.get_system<System>("RIPF-TimeDeriv");
+  System& RT = es.get_system<System>("RT");
+  const Parameters& P = es.parameters;
+  rdc_ripf_params p{};
+  p.time_step = detail::getR(P, "time_step");
+  p.VolFr_stroma = detail::getR(P, "volume_fraction/stroma"); p.VolFr_parenchyma = detail::getR(P, "volume_fraction/parenchyma");
+  p.VolFr_exponent = detail::getR(P, "volume_fraction/exponent"); p.VolFr_min_vacant = detail::getR(P, "volume_fraction/min_vacant");
+  p.VolFr_max_vacant = detail::getR(P, "volume_fraction/max_vacant");
+  p.phi_cc_B = detail::getR(P, "HU/phi/cc/build"); p.phi_cc_D = detail::getR(P, "HU/phi/cc/decay"); p.phi_cc = detail::getR(P, "HU/phi/cc/rate");
+  p.phi_fb_B = detail::getR(P, "HU/phi/fb/build"); p.phi_fb_D = detail::getR(P, "HU/phi/fb/decay"); p.phi_fb = detail::getR(P, "HU/phi/fb/rate");
+  p.phi_tol = detail::getR(P, "HU/phi/tolerance");
+  p.kappa = detail::getR(P, "cc/kappa"); p.kappa_RT_c = detail::getR(P, "cc/kappa/RT/c");
+  p.delta = detail::getR(P, "cc/delta"); p.delta_RT_a = detail::getR(P, "cc/delta/RT/a"); p.delta_RT_b = detail::getR(P, "cc/delta/RT/b");
+  p.lambda = detail::getR(P, "fb/lambda"); p.lambda_RT_r = detail::getR(P, "fb/lambda/RT/r"); p.lambda_HU_r = detail::getR(P, "fb/lambda/HU/r");
+  p.omicro = detail::getR(P, "fb/omicro"); p.omicro_RT_r = detail::getR(P, "fb/omicro/RT/r"); p.omicro_fb_b = detail::getR(P, "fb/omicro/fb/b");
+  p.omega = detail::getR(P, "fb/omega"); p.diffusion = detail::getR(P, "fb/diffusion");
+  p.haptotaxis = detail::getR(P, "fb/haptotaxis"); p.radiotaxis = detail::getR(P, "fb/radiotaxis");
+  p.RT_dose_total_max = P.get<int>("RT_dose/total/max");
+  const int64_t nn = es.get_mesh().n_nodes();
+  std::vector<double> aux((size_t)nn * 3);
+  for (int64_t n = 0; n < nn; n++) {
+    aux[(size_t)n * 3 + 0] = TD.current_solution((dof_id_type)(n * 3 + 1));  // cc__dtime, src/ripf.C:470
+    aux[(size_t)n * 3 + 1] = TD.current_solution((dof_id_type)(n * 3 + 2));  // fb__dtime, :471
+    aux[(size_t)n * 3 + 2] = RT.current_solution((dof_id_type)(n * 3 + 2));  // RT_dose/total, :477
+  }
+  rdc_ctx* c = es.context(system_name, 3);
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.old_local_solution.raw().data(), system.old_local_solution.size()), "old solution");
+  check(c, rdc_field_upload(c, RDC_FIELD_AUX_NODAL, aux.data(), (int64_t)aux.size()), "aux fields");
+  check(c, rdc_assemble_ripf(c, &p), "rdc_assemble_ripf");
+  detail::pull_results(c, system);
+}
+
+// src/coupled_hcc.C:414-649: assembled on the CURRENT node positions of the (moving) mesh
+inline void assemble_hcc(EquationSystems& es, const std::string& system_name) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  if (system.n_vars() != 3) throw std::runtime_error("assemble_hcc: system must have 3 variables (l,c,n)");
+  const Parameters& P = es.parameters;
+  rdc_hcc_params p{};
+  p.time_step = detail::getR(P, "time_step");
+  p.cells_min_capacity = detail::getR(P, "cells/min_capacity"); p.cells_max_capacity = detail::getR(P, "cells/max_capacity");
+  p.cells_max_capacity_exponent = detail::getR(P, "cells/max_capacity/exponent");
+  p.produce_l = detail::getR(P, "produce/l");
+  p.diffuse_c = detail::getR(P, "diffuse/c"); p.mechano_c = detail::getR(P, "mechano/c"); p.produce_c = detail::getR(P, "produce/c");
+  p.necrosis_l = detail::getR(P, "necrosis/l"); p.necrosis_c = detail::getR(P, "necrosis/c"); p.necrosis_pressure = detail::getR(P, "necrosis/pressure");
+  rdc_ctx* c = es.context(system_name, 3);
+  check(c, rdc_mesh_update_coords(c, es.get_mesh().coordinates().data()), "rdc_mesh_update_coords");
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.old_local_solution.raw().data(), system.old_local_solution.size()), "old solution");
+  check(c, rdc_assemble_hcc(c, &p), "rdc_assemble_hcc");
+  detail::pull_results(c, system);
+}
+
+}  // namespace host
+}  // namespace rdc
+#endif
