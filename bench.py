@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged halo, for rehearsing N > 1 on a 1-GPU box")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (rdc_set_option)")
-    ap.add_argument("--cpu-sample", type=int, default=60, help="K(m) sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=84, help="K(m) sample for the CPU baseline (0 = skip)")
     a = ap.parse_args()
 
     import torch

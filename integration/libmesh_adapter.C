@@ -1,0 +1,152 @@
+// libmesh_adapter.C — the reference-side binding: drop-in replacements for the static
+// assemble_<model>(EquationSystems&, const std::string&) callbacks of rdcFEs that forward to the
+// C-ABI of librdc_assembly.so.
+//
+// NOT COMPILED IN THIS REPOSITORY'S BUILD: it needs libMesh (d3bda6c) and PETSc (746207a), neither of
+// which exists in the build image.  It is written against the libMesh API the reference itself uses
+// (src/pihna.C:318-395, :752-755) and is exercised here only through its twin over the mock types,
+// rdcfes_amd/host/rdc_host.h, which makes exactly the same C-ABI calls in the same order.
+//
+// Usage in the reference tree:
+//   1. add this file to src/ (Makefile:7 globs src/*.C), link with -lrdc_assembly;
+//   2. in src/pihna.C replace   model.attach_assemble_function(assemble_pihna);          (:35)
+//      by                       model.attach_assemble_function(rdc_gpu::assemble_pihna);
+//      (same for src/ripf.C:27 and src/coupled_hcc.C:37).  Nothing else changes: libMesh still zeroes
+//      matrix/rhs, calls the callback once per time step on every rank, closes matrix/rhs and hands
+//      them to PETSc KSP.
+#include "libmesh/dof_map.h"
+#include "libmesh/elem.h"
+#include "libmesh/equation_systems.h"
+#include "libmesh/mesh_base.h"
+#include "libmesh/numeric_vector.h"
+#include "libmesh/petsc_matrix.h"
+#include "libmesh/transient_system.h"
+
+#include <map>
+#include <unordered_map>
+#include <vector>
+
+#include "rdc_assembly.h"
+
+using namespace libMesh;
+
+namespace rdc_gpu {
+
+// One GPU context per (rank, system): built on the first call, reused every time step.
+struct Binding {
+  rdc_ctx* ctx = nullptr;
+  std::vector<dof_id_type> local_to_global_node;   // local node id -> libMesh node id (owned first, then ghosts)
+  std::vector<PetscInt> row_ptr, col_glob;         // owned-row CSR with GLOBAL dof column ids
+  std::vector<double> val, rhs, u_old;
+  dof_id_type n_owned = 0;
+};
+
+static std::map<std::string, Binding> g_bindings;
+
+static void fail(rdc_ctx* c, const char* what) { libmesh_error_msg(std::string(what) + ": " + rdc_last_error(c)); }
+
+// Marshal the rank's partition once: owned nodes first, then ghost nodes; elements = every active
+// element touching an owned node (libMesh's active_local elements plus one ghost layer, which a
+// DistributedMesh / ghosted ReplicatedMesh already holds).
+static Binding& bind(EquationSystems& es, const std::string& name, unsigned int nvar) {
+  Binding& B = g_bindings[name];
+  if (B.ctx) return B;
+  const MeshBase& mesh = es.get_mesh();
+  const System& sys = es.get_system(name);
+  const processor_id_type me = mesh.processor_id();
+  std::unordered_map<dof_id_type, uint32_t> g2l;
+  for (const auto& node : mesh.local_node_ptr_range()) { g2l[node->id()] = (uint32_t)B.local_to_global_node.size(); B.local_to_global_node.push_back(node->id()); }
+  B.n_owned = (dof_id_type)B.local_to_global_node.size();
+  std::vector<uint32_t> conn;
+  std::vector<const Elem*> elems;
+  for (const auto& elem : mesh.active_element_ptr_range()) {
+    bool touches = false;
+    for (unsigned int i = 0; i < elem->n_nodes(); i++) touches |= (elem->node_ref(i).processor_id() == me);
+    if (touches) elems.push_back(elem);
+  }
+  const int nen = (int)elems.front()->n_nodes();   // TET4 (4) or HEX8 (8), one type per mesh
+  for (const Elem* elem : elems)
+    for (int i = 0; i < nen; i++) {
+      const dof_id_type g = elem->node_id(i);
+      auto it = g2l.find(g);
+      if (it == g2l.end()) { it = g2l.emplace(g, (uint32_t)B.local_to_global_node.size()).first; B.local_to_global_node.push_back(g); }
+      conn.push_back(it->second);
+    }
+  std::vector<double> xyz(3 * B.local_to_global_node.size());
+  for (size_t l = 0; l < B.local_to_global_node.size(); l++)
+    for (int d = 0; d < 3; d++) xyz[3 * l + d] = mesh.node_ref(B.local_to_global_node[l])(d);
+  int device = 0;  // one rank per GPU: e.g. local MPI rank
+  if (rdc_ctx_create(device, &B.ctx) != RDC_OK) libmesh_error_msg(rdc_last_error(nullptr));
+  if (rdc_mesh_upload(B.ctx, nen, (int64_t)elems.size(), (int64_t)B.local_to_global_node.size(), B.n_owned, conn.data(),
+                      xyz.data(), (int)nvar) != RDC_OK) fail(B.ctx, "rdc_mesh_upload");
+  // pattern with LOCAL column ids -> global PETSc dof ids (dof_number(sys, var, 0))
+  int64_t n_rows = 0, nnz = 0;
+  rdc_csr_dims(B.ctx, &n_rows, &nnz);
+  std::vector<int64_t> rp(n_rows + 1);
+  std::vector<int32_t> cl(nnz);
+  rdc_csr_pattern_download(B.ctx, rp.data(), cl.data());
+  B.row_ptr.assign(rp.begin(), rp.end());
+  B.col_glob.resize(nnz);
+  for (int64_t k = 0; k < nnz; k++) {
+    const Node& nd = mesh.node_ref(B.local_to_global_node[cl[k] / nvar]);
+    B.col_glob[k] = (PetscInt)nd.dof_number(sys.number(), cl[k] % nvar, 0);
+  }
+  B.val.resize(nnz); B.rhs.resize(n_rows); B.u_old.resize(nvar * B.local_to_global_node.size());
+  return B;
+}
+
+// old_local_solution (ghosted) -> [local node][var], the layout of RDC_FIELD_OLD_SOLUTION
+static void gather_old_solution(const EquationSystems& es, const TransientLinearImplicitSystem& sys, Binding& B, unsigned int nvar) {
+  const MeshBase& mesh = es.get_mesh();
+  for (size_t l = 0; l < B.local_to_global_node.size(); l++) {
+    const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+    for (unsigned int v = 0; v < nvar; v++) B.u_old[l * nvar + v] = sys.old_solution(nd.dof_number(sys.number(), v, 0));   // src/pihna.C:433
+  }
+}
+
+// assembled owned rows -> system.matrix / system.rhs (what add_matrix / add_vector did, src/pihna.C:754-755)
+static void push_results(const EquationSystems& es, TransientLinearImplicitSystem& sys, Binding& B, unsigned int nvar) {
+  if (rdc_csr_download(B.ctx, B.val.data(), B.rhs.data()) != RDC_OK) fail(B.ctx, "rdc_csr_download");
+  Mat A = cast_ref<PetscMatrix<Number>&>(*sys.matrix).mat();
+  const MeshBase& mesh = es.get_mesh();
+  for (dof_id_type l = 0; l < B.n_owned; l++) {
+    const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+    for (unsigned int a = 0; a < nvar; a++) {
+      const PetscInt row = (PetscInt)nd.dof_number(sys.number(), a, 0);
+      const PetscInt r = (PetscInt)(l * nvar + a), b = B.row_ptr[r], n = B.row_ptr[r + 1] - b;
+      MatSetValues(A, 1, &row, n, &B.col_glob[b], &B.val[b], INSERT_VALUES);   // complete rows: no off-rank stash traffic
+      sys.rhs->set(row, B.rhs[r]);
+    }
+  }
+}
+
+void assemble_pihna(EquationSystems& es, const std::string& system_name) {
+  TransientLinearImplicitSystem& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  libmesh_assert_equal_to(system.n_vars(), 5);
+  Binding& B = bind(es, system_name, 5);
+  rdc_pihna_params p;   // the same keys assemble_pihna reads, src/pihna.C:358-381
+  p.time_step = es.parameters.get<Real>("time_step");
+  p.cells_min_capacity = es.parameters.get<Real>("cells_min_capacity");
+  p.cells_max_capacity = es.parameters.get<Real>("cells_max_capacity");
+  p.cytokines_max_capacity = es.parameters.get<Real>("cytokines_max_capacity");
+  p.cells_max_capacity_exponent = es.parameters.get<Real>("cells_max_capacity/exponent");
+  p.necrosis_c = es.parameters.get<Real>("necrosis/c"); p.necrosis_h = es.parameters.get<Real>("necrosis/h"); p.necrosis_v = es.parameters.get<Real>("necrosis/v");
+  p.diffuse_c = es.parameters.get<Real>("diffuse/c"); p.taxis_c = es.parameters.get<Real>("taxis/c");
+  p.diffuse_h = es.parameters.get<Real>("diffuse/h"); p.taxis_h = es.parameters.get<Real>("taxis/h");
+  p.produce_c = es.parameters.get<Real>("produce/c");
+  p.switch_c2h = es.parameters.get<Real>("switch/c/to/h"); p.switch_h2c = es.parameters.get<Real>("switch/h/to/c"); p.switch_h2n = es.parameters.get<Real>("switch/h/to/n");
+  p.diffuse_v = es.parameters.get<Real>("diffuse/v"); p.taxis_v = es.parameters.get<Real>("taxis/v"); p.produce_v = es.parameters.get<Real>("produce/v");
+  p.secrete_a_c = es.parameters.get<Real>("secrete/a/from/c"); p.secrete_a_h = es.parameters.get<Real>("secrete/a/from/h");
+  p.uptake_a_v = es.parameters.get<Real>("uptake/a/from/v"); p.decay_a = es.parameters.get<Real>("decay/a");
+  gather_old_solution(es, system, B, 5);
+  if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
+  if (rdc_assemble_pihna(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_pihna");
+  push_results(es, system, B, 5);
+}
+
+// assemble_ripf / assemble_hcc follow the same pattern (parameter keys: src/ripf.C:377-408,
+// src/coupled_hcc.C:450-461; RIPF additionally gathers TD vars 1,2 and RT var 2 into
+// RDC_FIELD_AUX_NODAL; HCC calls rdc_mesh_update_coords with the current node positions first).
+// See rdcfes_amd/host/rdc_host.h::assemble_ripf / assemble_hcc for the exact call sequences.
+
+}  // namespace rdc_gpu
