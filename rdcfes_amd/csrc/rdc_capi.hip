@@ -31,6 +31,8 @@ struct rdc_ctx {
   int strategy = RDC_SCATTER_AUTO;
   int variant = RDC_VARIANT_AUTO;
   int opt_occ = 2, opt_ablate = 0, opt_kernel = 0;
+  int opt_special = 1;  // allow parameter-sparsity kernel variants
+  int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
   // device mesh data
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
@@ -161,6 +163,17 @@ int next_event_pair(rdc_ctx* c, hipEvent_t* start, hipEvent_t* stop) {
   return RDC_OK;
 }
 
+// parameter-sparsity specialisation: models may offer a variant with smaller structural masks that is
+// exact for the given parameter values (PIHNA with the cell transport terms off)
+template <class M, class P>
+hipError_t launch_specialised(const LaunchArgs& a, const typename M::K& k, const P&) { return launch_rd<M>(a, k); }
+template <>
+hipError_t launch_specialised<Pihna, rdc_pihna_params>(const LaunchArgs& a, const Pihna::K& k, const rdc_pihna_params& p) {
+  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && PihnaNoCellTransport::applies(p))
+    return launch_tet4_fast<PihnaNoCellTransport>(a, k);
+  return launch_rd<Pihna>(a, k);
+}
+
 template <class M, class P>
 int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (!c) return RDC_ERR_INVALID;
@@ -186,6 +199,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_occ = c->opt_occ;
   a.opt_ablate = c->opt_ablate;
   a.opt_kernel = c->opt_kernel;
+  a.opt_special = c->opt_special;
   if (c->prep.rg2_ok && c->prep.nen == 4) {
     a.rg2.n_wg = (int)c->prep.wg2.size();
     a.rg2.desc = (const HostPrep::WgDesc*)c->rg2_desc.p;
@@ -196,6 +210,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.pair_aux = (const uint16_t*)c->rg2_aux.p;
     a.rg2.node_tab = (const uint16_t*)c->rg2_ntab.p;
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
+    a.rg2.block = c->prep.rg2_block;
   }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
@@ -209,7 +224,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (c->timing) {
     if ((rc = next_event_pair(c, &a.ev_start, &ev_stop))) return rc;
   }
-  hipError_t e = launch_rd<M>(a, k);
+  hipError_t e = launch_specialised<M>(a, k, *p);
   if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   if (c->timing) RDC_HIP(c, hipEventRecord(ev_stop, c->stream));
   return RDC_OK;
@@ -296,6 +311,11 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   if (!c || !key) return RDC_ERR_INVALID;
   if (!std::strcmp(key, "occupancy")) c->opt_occ = value;
   else if (!std::strcmp(key, "ablate")) c->opt_ablate = value;
+  else if (!std::strcmp(key, "block")) {
+    if (value != 128 && value != 256) return fail(c, RDC_ERR_INVALID, "block must be 128 or 256");
+    c->opt_block = value;
+  }
+  else if (!std::strcmp(key, "specialise")) c->opt_special = value;
   else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = flat-list LDS row gather, 1 = first row-gather kernel, 2 = staged (deterministic) row gather
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
@@ -318,7 +338,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   c->have_mesh = false;
   // LDS budget of a row-gather workgroup: half the per-block limit keeps two workgroups per CU
   const size_t budget = c->max_lds >= 64 * 1024 ? 50 * 1024 : c->max_lds / 2;
-  std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, 256, c->prep);
+  std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, c->opt_block, c->prep);
   if (!err.empty()) return fail(c, RDC_ERR_INVALID, "%s", err.c_str());
   const HostPrep& P = c->prep;
   std::vector<uint32_t> conn_v(conn, conn + n_elem * elem_type);

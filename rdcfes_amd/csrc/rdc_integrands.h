@@ -242,6 +242,20 @@ struct Pihna {
   }
 };
 
+// PIHNA with the cell transport terms switched off: diffuse/c = taxis/c = diffuse/h = taxis/h = taxis/v = 0
+// exactly (the shipped run/PIHNA/input.dat; only diffuse/v is a transport term there).
+// Same point functions and coefficients; only the structural masks shrink, so the factored kernel
+// drops the identically-zero products (0 * finite = 0 upstream) instead of evaluating them.  The
+// host selects this variant from the parameter values; any non-zero entry uses Pihna.
+struct PihnaNoCellTransport : Pihna {
+  static inline bool applies(const rdc_pihna_params& p) {
+    return p.diffuse_c == 0.0 && p.taxis_c == 0.0 && p.diffuse_h == 0.0 && p.taxis_h == 0.0 && p.taxis_v == 0.0;
+  }
+  RDC_HD static constexpr bool hasB(int a, int b, int k) { return a == 3 && b < 4 && k == 2; }  // diffuse/v * dTau
+  RDC_HD static constexpr bool hasD(int a, int b) { return a == 3 && b == 3; }
+  RDC_HD static constexpr bool hasRG(int a, int k) { return a == 3 && k == 2; }
+};
+
 // =========================================================================================
 // RIPF: unknowns (HU, cc, fb); aux nodal (cc_dtime, fb_dtime, RT_total);
 // gradient fields k: 0 = fb, 1 = HU, 2 = RT_total (normalised to unit length, :481-484)

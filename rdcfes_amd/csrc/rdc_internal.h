@@ -24,6 +24,7 @@ struct Rg2Dev {
   const uint16_t* pair_aux = nullptr;
   const uint16_t* node_tab = nullptr;
   size_t lds_bytes = 0;
+  int block = 256;
 };
 
 // ---- kernel launch plumbing -----------------------------------------------------------------
@@ -34,7 +35,7 @@ struct LaunchArgs {
   const double* aux;
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
-  int opt_occ, opt_ablate, opt_kernel;  // tuning knobs (rdc_set_option)
+  int opt_occ, opt_ablate, opt_kernel, opt_special;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
   double* val;
   double* rhs;

@@ -225,7 +225,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
       if (np > block || nch + 1 > block || len > 255) { P.rg2_ok = false; break; }
       // gather work items of a workgroup: its chunks plus one rhs item per node
       if (n > wgp.back() && (pairs + np > block || chunks + nch + (n - wgp.back() + 1) > block || n - wgp.back() >= 255 ||
-                             n - wgp.back() >= HostPrep::RG3_DIAG_SLOTS / HostPrep::RG3_DIAG_COPIES ||
+                             n - wgp.back() >= HostPrep::RG3_DIAG_SLOTS / HostPrep::rg3_diag_copies(block) ||
                              bytes + nbytes + diag_area > lds_budget_bytes)) {
         wgp.push_back(n);
         pairs = 0;

@@ -67,8 +67,10 @@ struct HostPrep {
   // {rowoff, stride = nvar*len, rhsoff, pad, off[0..3] = nvar*slot of rotated column j}  (TET4 only)
   std::vector<uint16_t> pair_aux;   // [n_wg][block][8]
   size_t rg2_lds_bytes = 0;         // largest row slice (values + rhs + private diagonal copies) of a workgroup
-  static constexpr int RG3_DIAG_COPIES = 6;  // private accumulators of a node's diagonal block + rhs
-  static constexpr int RG3_DIAG_SLOTS = 64;  // fixed slot count (node * COPIES + copy) => at most 10 nodes per workgroup
+  // private accumulators of a node's diagonal block + rhs: one copy per lane of the node inside a wave
+  // (pairs of a node are dealt round-robin to the block/64 waves) => copies = 24 * 64 / block
+  static constexpr int rg3_diag_copies(int block) { return 1536 / block; }
+  static constexpr int RG3_DIAG_SLOTS = 64;  // fixed slot count (node * copies + copy) => 64 / copies nodes per workgroup
   std::vector<uint16_t> node_tab;   // [n_owned][4] {rowoff, stride, nvar*diag slot, 0}: where the diagonal block sits
   std::vector<Chunk> chunk;
   std::vector<StoreDesc> sdesc;     // [total node blocks]

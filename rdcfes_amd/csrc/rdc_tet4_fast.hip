@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(BLOCK, MINW)
 k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_rec,
            const uint16_t* __restrict__ pair_aux, const uint16_t* __restrict__ node_tab, const typename M::K k,
            const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs) {
-  constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::RG3_DIAG_COPIES, NDV = NV * NV + NV;
+  constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int w = blockIdx.x;
   // lane l of wave v takes pair l*NW + v (spreads the pairs of one node over the waves)
@@ -205,7 +205,7 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   __syncthreads();
   // fold the private copies: diagonal block values into the row slice, rhs straight to memory
   for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
-    const int n = x / NDV, v = x - n * NDV;
+    const int v = x / d.nnodes, n = x - v * d.nnodes;  // consecutive threads -> consecutive nodes (stride NC doubles)
     const double* src = lds + nval + v * ns + n * NC;
     double sum = 0.0;
 #pragma unroll
@@ -381,17 +381,20 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.opt_kernel == 0) {
-    constexpr int BLOCK = 256;
-#define RDC_RG3(MINW)                                                                                              \
+#define RDC_RG3(BLOCK, MINW)                                                                                       \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
                      a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs)
-    if (a.opt_occ == 1) RDC_RG3(1);
-    else if (a.opt_occ == 3) RDC_RG3(3);
-    else RDC_RG3(2);
+    if (a.rg2.block == 128) {  // MINW counts waves per SIMD: 2 means four 128-thread workgroups per CU
+      if (a.opt_occ == 1) RDC_RG3(128, 1); else RDC_RG3(128, 2);
+    } else {
+      if (a.opt_occ == 1) RDC_RG3(256, 1);
+      else if (a.opt_occ == 3) RDC_RG3(256, 3);
+      else RDC_RG3(256, 2);
+    }
 #undef RDC_RG3
     return hipGetLastError();
   }
-  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.opt_kernel == 2) {
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.opt_kernel == 2 && a.rg2.block == 256) {
     constexpr int BLOCK = 256;
 #define RDC_RG2(MINW)                                                                                              \
   hipLaunchKernelGGL((k_tet4_rg2<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), 0, a.stream, a.rg2.desc, \
@@ -409,7 +412,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   hipLaunchKernelGGL((k_tet4_rowgather<M, EXP_MODE, BLOCK, MINW, ABL>), dim3(a.n_wg), dim3(BLOCK), a.lds_bytes, a.stream, \
                      a.m, k, a.packed, a.val, a.rhs)
       // tuning variants exist for the PIHNA / cubic-exponent instantiation only
-      const bool lab = std::is_same<M, Pihna>::value && EXP_MODE == 3;
+      const bool lab = (std::is_same<M, Pihna>::value || std::is_same<M, PihnaNoCellTransport>::value) && EXP_MODE == 3;
       const int key = lab ? a.opt_occ * 10 + a.opt_ablate : 20;
       if (lab) {
         switch (key) {
@@ -446,6 +449,7 @@ hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k) {
 }
 
 template hipError_t launch_tet4_fast<Pihna>(const LaunchArgs&, const Pihna::K&);
+template hipError_t launch_tet4_fast<PihnaNoCellTransport>(const LaunchArgs&, const PihnaNoCellTransport::K&);
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
 

@@ -108,7 +108,7 @@ def make_prep(shim):
 
 def shim_rows(lib, model, nen, params, X, U, A=None, fast=False, force_general_pow=False):
     """all rows through the product's row function -> (Ke [nv*nen][nv*nen] var-major, Fe)"""
-    nv = {0: 5, 1: 3, 2: 3}[model]
+    nv = {0: 5, 1: 3, 2: 3, 3: 5}[model]
     X = np.ascontiguousarray(X, dtype=np.float64)
     U = np.ascontiguousarray(U, dtype=np.float64)
     A = None if A is None else np.ascontiguousarray(A, dtype=np.float64)

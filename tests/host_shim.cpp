@@ -113,6 +113,9 @@ int shim_row(int model, int nen, int fast, int force_general_pow, const void* pa
     case 0: return run<Pihna>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
     case 1: return run<Ripf>((const rdc_ripf_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
     case 2: return run<Hcc>((const rdc_hcc_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 3:  // PIHNA, cell-transport-off variant: only legal when the parameters allow it
+      if (!PihnaNoCellTransport::applies(*(const rdc_pihna_params*)params)) return 3;
+      return run<PihnaNoCellTransport>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
   }
   return 2;
 }
@@ -123,6 +126,7 @@ int shim_masks(int model, const void* params, const double* u, const double* aux
     case 0: return masks<Pihna>((const rdc_pihna_params*)params, u, aux, worst);
     case 1: return masks<Ripf>((const rdc_ripf_params*)params, u, aux, worst);
     case 2: return masks<Hcc>((const rdc_hcc_params*)params, u, aux, worst);
+    case 3: return masks<PihnaNoCellTransport>((const rdc_pihna_params*)params, u, aux, worst);
   }
   return 2;
 }

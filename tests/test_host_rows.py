@@ -108,3 +108,25 @@ def test_threshold_branches(oracle, shim):
             Ke1, Fe1 = shim_rows(shim, 0, 4, p, X, u, fast=fast)
             np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-12 * np.abs(Ke0).max())
             np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-12 * max(np.abs(Fe0).max(), 1e-300))
+
+
+def test_pihna_cell_transport_off_variant(oracle, shim):
+    """PihnaNoCellTransport (smaller structural masks) is exact when diffuse/c, taxis/c, diffuse/h, taxis/h, taxis/v
+    are zero -- the shipped input -- and is refused otherwise."""
+    import ctypes as C
+    for seed in range(4):
+        X, u, aux, p = _case(0, 4, 200 + seed, "shipped")
+        Ke0, Fe0 = oracle.element(0, 4, X, u, p)
+        Ke1, Fe1 = shim_rows(shim, 3, 4, p, X, u, fast=True)
+        np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-12 * np.abs(Ke0).max())
+        np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-12 * np.abs(Fe0).max())
+    # masks cover every non-zero coefficient for such parameters
+    w = C.c_double(-1.0)
+    un = np.ascontiguousarray(u[0])
+    assert shim.shim_masks(3, C.byref(p), un.ctypes.data_as(C.POINTER(C.c_double)), None, C.byref(w)) == 0 and w.value == 0.0
+    # with any cell transport term on, the variant must not be used
+    X, u, aux, pf = _case(0, 4, 1, "full")
+    acc, fe = np.empty((5, 5, 4)), np.empty(5)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    Xc, uc = np.ascontiguousarray(X), np.ascontiguousarray(u)
+    assert shim.shim_row(3, 4, 1, 0, C.byref(pf), dp(Xc), dp(uc), None, 0, dp(acc), dp(fe)) == 3

@@ -38,12 +38,22 @@ if aux is not None:
 ctx.set_scatter(a.scatter)
 ctx.timing_enable(True)
 res = {s: [] for s in a.sets}
+cur_block = 256
 for r in range(a.rounds):
     for s in a.sets:
-        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0)
-        for kv in s.split(","):
-            if "=" in kv:
-                k, v = kv.split("="); ctx.set_option(k, int(v))
+        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0); ctx.set_option("specialise", 1)
+        opts = dict(kv.split("=") for kv in s.split(",") if "=" in kv)
+        blk = int(opts.pop("block", 256))
+        if blk != cur_block:  # work lists depend on the workgroup size: rebuild
+            ctx.set_option("block", blk)
+            ctx.mesh_upload(4, conn, xyz, nv)
+            ctx.field_upload(FIELD_OLD_SOLUTION, u)
+            if aux is not None:
+                ctx.field_upload(FIELD_AUX_NODAL, aux)
+            ctx.set_scatter(a.scatter)
+            cur_block = blk
+        for k, v in opts.items():
+            ctx.set_option(k, int(v))
         run(p); ctx.synchronize(); ctx.timing_sum_ms()
         for _ in range(a.reps):
             run(p)
