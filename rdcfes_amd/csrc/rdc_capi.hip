@@ -31,6 +31,8 @@ struct rdc_ctx {
   int strategy = RDC_SCATTER_AUTO;
   int variant = RDC_VARIANT_AUTO;
   int opt_occ = 2, opt_ablate = 0, opt_kernel = 0;
+  int opt_xcd = 0;      // XCD-aware workgroup order of the row-gather kernel (measured: no gain, off)
+  int opt_sched = 1;    // LDS-conflict-aware pair schedule (takes effect at the next rdc_mesh_upload)
   int opt_special = 1;  // allow parameter-sparsity kernel variants
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
@@ -200,6 +202,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_ablate = c->opt_ablate;
   a.opt_kernel = c->opt_kernel;
   a.opt_special = c->opt_special;
+  a.opt_xcd = c->opt_xcd;
   if (c->prep.rg2_ok && c->prep.nen == 4) {
     a.rg2.n_wg = (int)c->prep.wg2.size();
     a.rg2.desc = (const HostPrep::WgDesc*)c->rg2_desc.p;
@@ -316,6 +319,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     c->opt_block = value;
   }
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
+  else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
+  else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
   else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = flat-list LDS row gather, 1 = first row-gather kernel, 2 = staged (deterministic) row gather
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
@@ -338,7 +343,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   c->have_mesh = false;
   // LDS budget of a row-gather workgroup: half the per-block limit keeps two workgroups per CU
   const size_t budget = c->max_lds >= 64 * 1024 ? 50 * 1024 : c->max_lds / 2;
-  std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, c->opt_block, c->prep);
+  std::string err = prep_build(elem_type, n_elem, n_node, n_owned, conn, nvar, budget, c->opt_block, c->prep, c->opt_sched != 0);
   if (!err.empty()) return fail(c, RDC_ERR_INVALID, "%s", err.c_str());
   const HostPrep& P = c->prep;
   std::vector<uint32_t> conn_v(conn, conn + n_elem * elem_type);

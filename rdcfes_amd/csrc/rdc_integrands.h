@@ -51,19 +51,6 @@ struct Coef {
   }
 };
 
-// x^e for the crowding functions.  The reference calls pow(1-Te, ek) with a real exponent
-// (src/pihna.C:466); for the small integer exponents of the shipped inputs (ek = 3) the host
-// selects EXP_MODE = that integer and the power is formed by multiplication (<= 1 ulp from pow).
-// EXP_MODE 0 = general real exponent.  p = x^e, pm1 = x^(e-1).
-template <int EXP_MODE>
-RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
-  if (EXP_MODE == 1) { pm1 = 1.0; p = x; }
-  else if (EXP_MODE == 2) { pm1 = x; p = x * x; }
-  else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
-  else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
-  else { p = pow(x, e); pm1 = pow(x, e - 1.0); }
-}
-
 // 1/x.  The reference divides (IEEE); on the device a correctly rounded FP64 division costs ~11
 // instructions, so quotients sharing a denominator use one reciprocal: v_rcp_f64 (~1e-8 rel) plus
 // two Newton steps (<= 1 ulp off the IEEE quotient, far inside the 1e-10 parity bound).
@@ -79,6 +66,20 @@ RDC_HD double rcp(double x) {
 #else
   return 1.0 / x;
 #endif
+}
+
+// x^e for the crowding functions.  The reference calls pow(1-Te, ek) with a real exponent
+// (src/pihna.C:466); for the small integer exponents of the shipped inputs (ek = 3) the host
+// selects EXP_MODE = that integer and the power is formed by multiplication (<= 1 ulp from pow).
+// EXP_MODE 0 = general real exponent: one pow() and one reciprocal instead of upstream's two pow() calls
+// (x^(e-1) = x^e / x, exact to an ulp).  p = x^e, pm1 = x^(e-1).
+template <int EXP_MODE>
+RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
+  if (EXP_MODE == 1) { pm1 = 1.0; p = x; }
+  else if (EXP_MODE == 2) { pm1 = x; p = x * x; }
+  else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
+  else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
+  else { p = pow(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
 }
 
 // =========================================================================================

@@ -35,7 +35,7 @@ struct LaunchArgs {
   const double* aux;
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
-  int opt_occ, opt_ablate, opt_kernel, opt_special;  // tuning knobs (rdc_set_option)
+  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
   double* val;
   double* rhs;

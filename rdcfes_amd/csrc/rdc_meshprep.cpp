@@ -5,6 +5,7 @@
 //   * greedy element colouring + first-writer masks (coloured scatter needs no memset, no atomics)
 //   * (node, incident element) pairs and workgroup ranges for the row-gather kernels
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 
@@ -13,7 +14,7 @@
 namespace rdc {
 
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,
-                       int nvar, size_t lds_budget_bytes, int block, HostPrep& P) {
+                       int nvar, size_t lds_budget_bytes, int block, HostPrep& P, bool conflict_aware) {
   if (nen != 4 && nen != 8) return "element type must be TET4 (4) or HEX8 (8)";
   if (n_elem < 0 || n_node <= 0 || n_owned < 0 || n_owned > n_node) return "bad mesh sizes";
   if (n_node >= (int64_t)1 << 31) return "more than 2^31 local nodes not supported";
@@ -312,12 +313,80 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         }
         d.nout = extra;
         if (extra > block) fail_flag = 1;
+        // ---- LDS-conflict-aware schedule (TET4) ---------------------------------------------------
+        // The kernel maps pair index idx -> (wave = idx % NW, lane = idx / NW).  An FP64 LDS atomic costs
+        // 6 CU-cycles per wave-instruction on distinct banks, ~19 on random addresses and >50 when lanes
+        // share an address (tools/lds_atomic_bench.hip), so the host chooses, per pair, the wave and the
+        // ORDER of its three off-diagonal columns (any vertex permutation of a tet is legal) that adds the
+        // fewest bank / address collisions to the three off-diagonal instruction streams of that wave.
+        const int NW = block / 64, NCOP = HostPrep::rg3_diag_copies(block);
+        const int np_w = d.np;
+        std::vector<int> new_idx((size_t)np_w);
+        std::vector<std::array<int, 4>> col_of((size_t)np_w);  // rotated column j -> original local index
+        std::vector<int> copy_of((size_t)np_w, 0);
+        if (nen == 4 && conflict_aware) {
+          std::vector<int> lanes_used((size_t)NW, 0);
+          std::vector<std::array<std::array<uint8_t, 32>, 3>> bank((size_t)NW);
+          for (auto& bw : bank) for (auto& bj : bw) bj.fill(0);
+          const int naddr = nvar * nvar * d.nb + 1;
+          std::vector<uint8_t> addr_seen((size_t)NW * 3 * naddr, 0);  // [wave][j][address]: already targeted
+          std::vector<int> node_in_wave((size_t)NW * (size_t)(n1 - n0), 0);
+          static const int PERM[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+          for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
+            const int64_t e = inc_elem[p];
+            const int i = inc_loc[p];
+            const int64_t I = conn[e * nen + i];
+            const int idx = (int)(p - inc_ptr[n0]);
+            const int rowoff = (int)((int64_t)nvar * nvar * (P.bptr[I] - d.bb0));
+            int base[3], addr[3];
+            for (int c = 0; c < 3; c++) {
+              base[c] = (c + 1) ^ i;  // the three non-row local indices
+              addr[c] = rowoff + nvar * P.eslot[(size_t)e * 16 + i * 4 + base[c]];
+            }
+            int best_w = -1, best_q = 0;
+            long best_cost = -1;
+            for (int wv = 0; wv < NW; wv++) {
+              if (lanes_used[wv] >= 64 || node_in_wave[(size_t)wv * (n1 - n0) + (I - n0)] >= NCOP) continue;
+              for (int q = 0; q < 6; q++) {
+                long cost = lanes_used[wv];  // mild preference for the emptiest wave (load balance)
+                for (int j = 0; j < 3; j++) {
+                  const int ad = addr[PERM[q][j]];
+                  cost += 8L * bank[wv][j][ad & 31];
+                  if (addr_seen[((size_t)wv * 3 + j) * naddr + ad]) cost += 1000;
+                }
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_w = wv; best_q = q; }
+              }
+            }
+            if (best_w < 0) { fail_flag = 1; best_w = 0; }
+            new_idx[idx] = lanes_used[best_w] * NW + best_w;
+            copy_of[idx] = node_in_wave[(size_t)best_w * (n1 - n0) + (I - n0)]++;
+            lanes_used[best_w]++;
+            col_of[idx][0] = i;
+            for (int j = 0; j < 3; j++) {
+              const int ad = addr[PERM[best_q][j]];
+              col_of[idx][j + 1] = base[PERM[best_q][j]];
+              bank[best_w][j][ad & 31]++;
+              addr_seen[((size_t)best_w * 3 + j) * naddr + ad] = 1;
+            }
+          }
+          for (int wv = 0; wv < NW; wv++)
+            if (lanes_used[wv] * NW + wv - NW >= block) fail_flag = 1;
+        } else {
+          for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
+            const int idx = (int)(p - inc_ptr[n0]);
+            const int i = inc_loc[p];
+            new_idx[idx] = idx;
+            copy_of[idx] = (idx / NW) % NCOP;
+            for (int j = 0; j < nen && j < 4; j++) col_of[idx][j] = (nen == 4) ? (j ^ i) : 0;
+          }
+        }
         // pair records and contribution entries in ascending pair order -> fixed summation order
         for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
           const int64_t e = inc_elem[p];
           const int i = inc_loc[p];
           const int64_t I = conn[e * nen + i];
-          const int64_t idx = p - inc_ptr[n0];
+          const int64_t idx = new_idx[(size_t)(p - inc_ptr[n0])];
+          const std::array<int, 4>& cols = col_of[(size_t)(p - inc_ptr[n0])];
           uint32_t* pr = &P.pair_rec[((size_t)w * block + idx) * nen];
           if (nen == 4) {
             uint16_t* ax = &P.pair_aux[((size_t)w * block + idx) * 8];
@@ -327,11 +396,11 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
             ax[0] = (uint16_t)rowoff;
             ax[1] = (uint16_t)(nvar * len);
             ax[2] = (uint16_t)((I - n0) * nvar);
-            ax[3] = 0;
-            for (int j = 0; j < 4; j++) ax[4 + j] = (uint16_t)(nvar * P.eslot[(size_t)e * 16 + i * 4 + (j ^ i)]);
+            ax[3] = (uint16_t)copy_of[(size_t)(p - inc_ptr[n0])];  // private diagonal copy of this lane
+            for (int j = 0; j < 4; j++) ax[4 + j] = (uint16_t)(nvar * P.eslot[(size_t)e * 16 + i * 4 + cols[j]]);
           }
           for (int j = 0; j < nen; j++) {
-            const int jo = (nen == 4) ? (j ^ i) : ((j + i) % nen);  // rotation: row node first
+            const int jo = (nen == 4) ? cols[j] : ((j + i) % nen);  // row node first
             pr[j] = conn[e * nen + jo];
             const int lb = (int)(P.bptr[I] + P.eslot[(size_t)e * nen * nen + i * nen + jo] - d.bb0);
             P.contrib[d.c0 + cbeg[lb] + fill[lb]++] = (uint16_t)(idx * stride + (j == 0 ? 0 : j * nvar + 1));

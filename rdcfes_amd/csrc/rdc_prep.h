@@ -79,7 +79,7 @@ struct HostPrep {
 
 // returns empty string on success, else an error message
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,
-                       int nvar, size_t lds_budget_bytes, int block, HostPrep& out);
+                       int nvar, size_t lds_budget_bytes, int block, HostPrep& out, bool conflict_aware = true);
 
 }  // namespace rdc
 #endif

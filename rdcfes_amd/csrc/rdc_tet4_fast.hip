@@ -170,10 +170,17 @@ template <class M, int EXP_MODE, int BLOCK, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW)
 k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_rec,
            const uint16_t* __restrict__ pair_aux, const uint16_t* __restrict__ node_tab, const typename M::K k,
-           const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs) {
+           const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int xcd_remap) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int w = blockIdx.x;
+  // workgroups are dealt round-robin to the 8 XCDs (observed, used for speed only): give each XCD a
+  // contiguous range of the node ordering so neighbouring workgroups share node records in ONE L2
+  // (bijection for any grid size: XCD x owns q + (x < r) consecutive workgroups)
+  int w = blockIdx.x;
+  if (xcd_remap) {
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
+    w = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+  }
   // lane l of wave v takes pair l*NW + v (spreads the pairs of one node over the waves)
   const int idx = (threadIdx.x & 63) * NW + (threadIdx.x >> 6);
   const uint4 pr = reinterpret_cast<const uint4*>(pair_rec)[(int64_t)w * BLOCK + idx];
@@ -196,8 +203,8 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     LdsSink3<M> sink;
     sink.row = lds + (ax.x & 0xFFFF);
     sink.stride = (int)(ax.x >> 16);
-    // the pairs of a node that share a wave have consecutive idx / NW: distinct copies (mod NC)
-    sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (idx / NW) % NC;
+    // the host gives the pairs of a node that share a wave distinct copy indices (pair_aux[3])
+    sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
     sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
     sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
     tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
@@ -383,7 +390,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.opt_kernel == 0) {
 #define RDC_RG3(BLOCK, MINW)                                                                                       \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
-                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs)
+                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs, a.opt_xcd)
     if (a.rg2.block == 128) {  // MINW counts waves per SIMD: 2 means four 128-thread workgroups per CU
       if (a.opt_occ == 1) RDC_RG3(128, 1); else RDC_RG3(128, 2);
     } else {

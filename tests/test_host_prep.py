@@ -101,27 +101,25 @@ def _replay_rowgather(P, conn, nen, nv, n_owned, rows_of):
     return val, rhs
 
 
-def _rot(nen, j, i):
-    return (j ^ i) if nen == 4 else (j + i) % nen
-
-
 def _pair_rows(P, conn, nen, rows_of, w, cache):
-    """(pair index -> (Ke, Fe, element, local row index)) for the flat work lists of workgroup w"""
+    """{pair slot -> (Ke, Fe, element, local row index, cols)} for the flat work lists of workgroup w.
+    cols[j] = original local index of rotated column j (the host may permute the off-diagonal columns)."""
     d = P.wg2[w]
     B = P.rg2_block
-    out = []
-    for idx in range(d["np"]):
+    out = {}
+    for idx in range(B):
         nodes = P.pair_rec[(w * B + idx) * nen:(w * B + idx + 1) * nen]
-        # recover (element, i) from the pair record: the row node is first, the others rotated
+        if nodes[0] == 0xFFFFFFFF:
+            continue
         I = int(nodes[0])
-        cand = [(e, i) for e in np.nonzero((conn == I).any(axis=1))[0] for i in range(nen)
-                if conn[e, i] == I and all(conn[e, _rot(nen, j, i)] == nodes[j] for j in range(nen))]
-        assert len(cand) >= 1
-        e, i = cand[0]
+        cand = [e for e in np.nonzero((conn == I).any(axis=1))[0] if sorted(conn[e].tolist()) == sorted(nodes.tolist())]
+        assert len(cand) == 1
+        e = cand[0]
+        cols = [int(np.nonzero(conn[e] == nodes[j])[0][0]) for j in range(nen)]
         if e not in cache:
             cache[e] = rows_of(e)
-        out.append((cache[e][0], cache[e][1], e, i))
-    assert np.all(P.pair_rec[(w * B + d["np"]) * nen:(w + 1) * B * nen] == 0xFFFFFFFF)
+        out[idx] = (cache[e][0], cache[e][1], e, cols[0], cols)
+    assert len(out) == d["np"]
     return out
 
 
@@ -135,13 +133,18 @@ def _replay_flat_lds(P, conn, nen, nv, n_owned, rows_of):
         nval, nrhs = d["nb"] * nv * nv, d["nnodes"] * nv
         assert 8 * (nval + nrhs) <= P.rg2_lds_bytes
         lds = np.zeros(nval + nrhs)
-        for idx, (Ke, Fe, e, i) in enumerate(_pair_rows(P, conn, nen, rows_of, w, cache)):
+        seen_copies = {}
+        for idx, (Ke, Fe, e, i, cols) in _pair_rows(P, conn, nen, rows_of, w, cache).items():
             ax = P.pair_aux[(w * B + idx) * 8:(w * B + idx + 1) * 8]
             rowoff, stride, rhsoff, off = int(ax[0]), int(ax[1]), int(ax[2]), ax[4:8].astype(int)
+            # pairs of one node inside one wave (idx % NW) must own distinct private diagonal copies
+            key = (idx % (B // 64), rhsoff, int(ax[3]))
+            assert key not in seen_copies and int(ax[3]) < 1536 // B
+            seen_copies[key] = 1
             for a in range(nv):
                 lds[nval + rhsoff + a] += Fe[a * nen + i]
                 for j in range(nen):
-                    jo = _rot(nen, j, i)
+                    jo = cols[j]
                     for b in range(nv):
                         lds[rowoff + a * stride + off[j] + b] += Ke[a * nen + i, b * nen + jo]
         val[d["vb0"]:d["vb0"] + nval] = lds[:nval]
@@ -164,9 +167,9 @@ def _replay_staged(P, conn, nen, nv, n_owned, rows_of):
         assert d["nout"] <= P.rg2_block and d["nch"] <= P.rg2_block and chunks["cnt"].max() <= 6
         for a in range(nv):
             stage = np.full(P.rg2_block * stride, np.nan)
-            for idx, (Ke, Fe, e, i) in enumerate(pairs):
+            for idx, (Ke, Fe, e, i, cols) in pairs.items():
                 for j in range(nen):
-                    jo = _rot(nen, j, i)
+                    jo = cols[j]
                     for b in range(nv):
                         stage[idx * stride + (b if j == 0 else j * nv + 1 + b)] = Ke[a * nen + i, b * nen + jo]
                 stage[idx * stride + nv] = Fe[a * nen + i]

@@ -38,14 +38,15 @@ if aux is not None:
 ctx.set_scatter(a.scatter)
 ctx.timing_enable(True)
 res = {s: [] for s in a.sets}
-cur_block = 256
+cur_block = 2561
 for r in range(a.rounds):
     for s in a.sets:
         ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0); ctx.set_option("specialise", 1)
         opts = dict(kv.split("=") for kv in s.split(",") if "=" in kv)
-        blk = int(opts.pop("block", 256))
-        if blk != cur_block:  # work lists depend on the workgroup size: rebuild
-            ctx.set_option("block", blk)
+        blk = int(opts.pop("block", 256)) * 10 + int(opts.pop("schedule", 1))
+        if blk != cur_block:  # work lists depend on the workgroup size / schedule: rebuild
+            ctx.set_option("block", blk // 10)
+            ctx.set_option("schedule", blk % 10)
             ctx.mesh_upload(4, conn, xyz, nv)
             ctx.field_upload(FIELD_OLD_SOLUTION, u)
             if aux is not None:
