@@ -32,6 +32,7 @@ struct rdc_ctx {
   int variant = RDC_VARIANT_AUTO;
   int opt_occ = 2, opt_ablate = 0, opt_kernel = 0;
   int opt_xcd = 0;      // XCD-aware workgroup order of the row-gather kernel (measured: no gain, off)
+  int opt_grid = 0;     // persistent grid size of the pipelined kernel (0 = 2 workgroups per CU)
   int opt_sched = 1;    // LDS-conflict-aware pair schedule (takes effect at the next rdc_mesh_upload)
   int opt_special = 1;  // allow parameter-sparsity kernel variants
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
@@ -40,7 +41,7 @@ struct rdc_ctx {
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
       wg_node_ptr;
   DevBuf val, rhs, packed;
-  DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab;
+  DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab, rg4_nlist, rg4_ploc;
   DevBuf field[RDC_FIELD_COUNT];
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
   // solid
@@ -203,6 +204,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_kernel = c->opt_kernel;
   a.opt_special = c->opt_special;
   a.opt_xcd = c->opt_xcd;
+  a.opt_grid = c->opt_grid;
   if (c->prep.rg2_ok && c->prep.nen == 4) {
     a.rg2.n_wg = (int)c->prep.wg2.size();
     a.rg2.desc = (const HostPrep::WgDesc*)c->rg2_desc.p;
@@ -212,6 +214,11 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.contrib = (const uint16_t*)c->rg2_contrib.p;
     a.rg2.pair_aux = (const uint16_t*)c->rg2_aux.p;
     a.rg2.node_tab = (const uint16_t*)c->rg2_ntab.p;
+    if (c->prep.rg4_nl_stride > 0) {
+      a.rg2.nlist = (const uint32_t*)c->rg4_nlist.p;
+      a.rg2.pair_loc = (const uint32_t*)c->rg4_ploc.p;
+      a.rg2.nl_stride = c->prep.rg4_nl_stride;
+    }
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
     a.rg2.block = c->prep.rg2_block;
   }
@@ -272,7 +279,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
-                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab,
+                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
@@ -321,6 +328,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
   else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
+  else if (!std::strcmp(key, "grid")) c->opt_grid = value;
   else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = flat-list LDS row gather, 1 = first row-gather kernel, 2 = staged (deterministic) row gather
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
@@ -367,6 +375,10 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
     if ((rc = dev_upload(c, c->rg2_contrib, P.contrib))) return rc;
     if ((rc = dev_upload(c, c->rg2_aux, P.pair_aux))) return rc;
     if ((rc = dev_upload(c, c->rg2_ntab, P.node_tab))) return rc;
+    if (P.rg4_nl_stride > 0) {
+      if ((rc = dev_upload(c, c->rg4_nlist, P.nlist))) return rc;
+      if ((rc = dev_upload(c, c->rg4_ploc, P.pair_loc))) return rc;
+    }
   }
   const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
   if ((rc = dev_alloc(c, c->val, nnz * sizeof(double)))) return rc;

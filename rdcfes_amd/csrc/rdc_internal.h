@@ -23,6 +23,9 @@ struct Rg2Dev {
   const uint16_t* contrib = nullptr;
   const uint16_t* pair_aux = nullptr;
   const uint16_t* node_tab = nullptr;
+  const uint32_t* nlist = nullptr;
+  const uint32_t* pair_loc = nullptr;
+  int nl_stride = 0;
   size_t lds_bytes = 0;
   int block = 256;
 };
@@ -35,7 +38,7 @@ struct LaunchArgs {
   const double* aux;
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
-  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd;  // tuning knobs (rdc_set_option)
+  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
   double* val;
   double* rhs;

@@ -408,8 +408,46 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         }
       }
       if (fail_flag) P.rg2_ok = false;
+      // ---- node lists of the workgroups (rg4) --------------------------------------------------
+      if (P.rg2_ok && nen == 4) {
+        std::vector<int32_t> nuniq((size_t)nwg, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int64_t w = 0; w < nwg; w++) {
+          std::vector<uint32_t> tmp(P.pair_rec.begin() + (size_t)w * block * 4, P.pair_rec.begin() + (size_t)(w + 1) * block * 4);
+          std::sort(tmp.begin(), tmp.end());
+          tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+          if (!tmp.empty() && tmp.back() == 0xFFFFFFFFu) tmp.pop_back();
+          nuniq[w] = (int32_t)tmp.size();
+        }
+        int mx = 1;
+        for (int64_t w = 0; w < nwg; w++) mx = std::max(mx, nuniq[w]);
+        if (mx <= 256) {
+          P.rg4_nl_stride = (mx + 63) & ~63;
+          P.nlist.assign((size_t)nwg * P.rg4_nl_stride, 0);
+          P.pair_loc.assign((size_t)nwg * block, 0xFFFFFFFFu);
+#pragma omp parallel for schedule(dynamic, 256)
+          for (int64_t w = 0; w < nwg; w++) {
+            const uint32_t* pr = &P.pair_rec[(size_t)w * block * 4];
+            std::vector<uint32_t> tmp(pr, pr + (size_t)block * 4);
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            if (!tmp.empty() && tmp.back() == 0xFFFFFFFFu) tmp.pop_back();
+            uint32_t* nl = &P.nlist[(size_t)w * P.rg4_nl_stride];
+            for (int x = 0; x < P.rg4_nl_stride; x++) nl[x] = tmp.empty() ? 0u : tmp[(size_t)std::min<size_t>(x, tmp.size() - 1)];
+            for (int idx = 0; idx < block; idx++) {
+              if (pr[idx * 4] == 0xFFFFFFFFu) continue;
+              uint32_t packed = 0;
+              for (int j = 0; j < 4; j++) {
+                const uint32_t li = (uint32_t)(std::lower_bound(tmp.begin(), tmp.end(), pr[idx * 4 + j]) - tmp.begin());
+                packed |= li << (8 * j);
+              }
+              P.pair_loc[(size_t)w * block + idx] = packed;
+            }
+          }
+        }
+      }
     }
-    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); }
+    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); P.nlist.clear(); P.pair_loc.clear(); P.rg4_nl_stride = 0; }
   }
   return std::string();
 }

@@ -72,6 +72,11 @@ struct HostPrep {
   static constexpr int rg3_diag_copies(int block) { return 1536 / block; }
   static constexpr int RG3_DIAG_SLOTS = 64;  // fixed slot count (node * copies + copy) => 64 / copies nodes per workgroup
   std::vector<uint16_t> node_tab;   // [n_owned][4] {rowoff, stride, nvar*diag slot, 0}: where the diagonal block sits
+  // persistent pipelined kernel ("rg4"): the distinct nodes a workgroup touches, so their records can be
+  // prefetched into LDS by LDS-DMA; pairs then address nodes by an 8-bit index into that list
+  int rg4_nl_stride = 0;            // list length per workgroup (multiple of 64, max over workgroups)
+  std::vector<uint32_t> nlist;      // [n_wg][rg4_nl_stride] node ids, padded with the first id
+  std::vector<uint32_t> pair_loc;   // [n_wg][block] four 8-bit list indices (row node in the low byte); ~0u = no pair
   std::vector<Chunk> chunk;
   std::vector<StoreDesc> sdesc;     // [total node blocks]
   std::vector<uint16_t> contrib;    // stage index (doubles) of the contribution: pair * stride + slot(column), see rdc_meshprep.cpp

@@ -230,6 +230,132 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   for (int x = threadIdx.x; x < nval; x += BLOCK) __builtin_nontemporal_store(lds[x], out + x);
 }
 
+// ---- persistent, software-pipelined row gather -----------------------------------------------
+// Same arithmetic and LDS accumulation as k_tet4_rg3, but a workgroup loops over work items
+// (w = blockIdx.x, += gridDim.x) and, while it evaluates item w, the data of item w + gridDim.x is
+// already on its way into LDS by LDS-DMA (global_load_lds: no VGPR destination): the node records
+// of the item's distinct nodes (gathered through its node list) and its pair records.  A node
+// record is fetched once per workgroup instead of once per pair, pairs address nodes by 8-bit list
+// indices, and the ~2 us dependent load phase of every item overlaps the previous item's compute.
+template <class M, int EXP_MODE, int BLOCK, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW)
+k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_loc,
+           const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
+           const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
+           double* __restrict__ val, double* __restrict__ rhs, const int nwg, const int nl_stride,
+           const int acc_doubles) {
+  constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
+  constexpr int ns = HostPrep::RG3_DIAG_SLOTS, NP = Rec<M>::N / 2;  // NP 16-byte pieces per node record
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  // LDS map: [accumulators: row slice | private diagonals] [2 x (records | pair_aux | pair_loc)]
+  const int rec_doubles = NP * nl_stride * 2;
+  const int buf_doubles = rec_doubles + BLOCK * 2 + BLOCK / 2;
+  double* const bufs = lds + acc_doubles;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = lane * NW + wv;  // pair slot of this thread (see k_tet4_rg3)
+  const int rounds = nl_stride >> 6;
+  const int G = gridDim.x;
+
+  // all LDS-DMA of one work item: records (wave r gathers list entries [64r, 64r+64)), pair records
+  auto prefetch = [&](int item, uint32_t nid, int b) {
+    double* base = bufs + b * buf_doubles;
+    if (wv < rounds) {
+      const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
+#pragma unroll
+      for (int p = 0; p < NP; p++)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(base + (p * nl_stride + wv * 64) * 2), 16, 0, 0);
+    }
+    const char* ax = reinterpret_cast<const char*>(pair_aux) + ((size_t)item * BLOCK + threadIdx.x) * 16;
+    __builtin_amdgcn_global_load_lds((glb_ptr)ax, (lds_ptr)(base + rec_doubles + wv * 128), 16, 0, 0);
+    const char* pl = reinterpret_cast<const char*>(pair_loc) + ((size_t)item * BLOCK + threadIdx.x) * 4;
+    __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(base + rec_doubles + BLOCK * 2 + wv * 32), 4, 0, 0);
+  };
+
+  int w = blockIdx.x;
+  if (w >= nwg) return;
+  // ---- prologue: first item's data, second item's node ids; accumulators start at zero -------------
+  uint32_t nid_next = 0;
+  {
+    const uint32_t nid0 = (wv < rounds) ? nlist[(size_t)w * nl_stride + wv * 64 + lane] : 0u;
+    prefetch(w, nid0, 0);
+    if (w + G < nwg && wv < rounds) nid_next = nlist[(size_t)(w + G) * nl_stride + wv * 64 + lane];
+    for (int x = threadIdx.x; x < acc_doubles; x += BLOCK) lds[x] = 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int it = 0; w < nwg; it++, w += G) {
+    const int b = it & 1;
+    const HostPrep::WgDesc d = desc[w];
+    const int wn = w + G;
+    uint32_t nid_n2 = 0;
+    if (wn < nwg) {  // buffer b^1 was last read before the barriers that ended the previous iteration
+      prefetch(wn, nid_next, b ^ 1);
+      if (wn + G < nwg && wv < rounds) nid_n2 = nlist[(size_t)(wn + G) * nl_stride + wv * 64 + lane];
+    }
+    const double* base = bufs + b * buf_doubles;
+    const uint4 ax = reinterpret_cast<const uint4*>(base + rec_doubles)[idx];
+    const uint32_t pl = reinterpret_cast<const uint32_t*>(base + rec_doubles + BLOCK * 2)[idx];
+    const int nval = d.nb * NV * NV;
+    if (pl != 0xFFFFFFFFu) {
+      double X[4][3], U[4][NV], AX[4][M::NAUX > 0 ? M::NAUX : 1];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int li = (pl >> (8 * j)) & 0xFF;
+        double r[2 * NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          const double2 v2 = reinterpret_cast<const double2*>(base)[p * nl_stride + li];
+          r[2 * p] = v2.x; r[2 * p + 1] = v2.y;
+        }
+        X[j][0] = r[0]; X[j][1] = r[1]; X[j][2] = r[2];
+#pragma unroll
+        for (int v = 0; v < NV; v++) U[j][v] = r[3 + v];
+        if (M::NAUX > 0) {
+#pragma unroll
+          for (int v = 0; v < M::NAUX; v++) AX[j][v] = r[3 + NV + v];
+        } else {
+          AX[j][0] = 0.0;
+        }
+      }
+      LdsSink3<M> sink;
+      sink.row = lds + (ax.x & 0xFFFF);
+      sink.stride = (int)(ax.x >> 16);
+      sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
+      sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
+      sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
+      tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
+    }
+    // the next item's LDS-DMA was issued a whole compute phase ago: this wait does not stall
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // fold the private copies (and clear them for the next item)
+    for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
+      const int v = x / d.nnodes, n = x - v * d.nnodes;
+      double* src = lds + nval + v * ns + n * NC;
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; c++) { sum += src[c]; src[c] = 0.0; }
+      if (v < NV * NV) {
+        const uint2 nt = reinterpret_cast<const uint2*>(node_tab)[d.n0 + n];
+        const int a = v / NV, bb = v - a * NV;
+        lds[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + bb] = sum;
+      } else {
+        rhs[(int64_t)(d.n0 + n) * NV + (v - NV * NV)] = sum;
+      }
+    }
+    __syncthreads();
+    double* out = val + d.vb0;
+    for (int x = threadIdx.x; x < nval; x += BLOCK) {
+      __builtin_nontemporal_store(lds[x], out + x);
+      lds[x] = 0.0;  // accumulators are cleared by their last reader: no separate zero pass
+    }
+    __syncthreads();
+    nid_next = nid_n2;
+  }
+}
+
 // ---- staged row gather (the default TET4 path) ----------------------------------------------
 // One thread per (row node, incident element) pair evaluates one equation row at a time into an
 // LDS stage buffer with plain stores; after a barrier the same workgroup sums, for every node
@@ -387,6 +513,22 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
+      a.opt_kernel == 4) {
+    constexpr int BLOCK = 256;
+    const int nl = a.rg2.nl_stride;
+    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
+    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + 2 * ((size_t)(Rec<M>::N / 2) * nl * 2 + BLOCK * 2 + BLOCK / 2));
+    int grid = a.opt_grid > 0 ? a.opt_grid : 512;
+    if (grid > a.rg2.n_wg) grid = a.rg2.n_wg;
+#define RDC_RG4(MINW)                                                                                              \
+  hipLaunchKernelGGL((k_tet4_rg4<M, EXP_MODE, BLOCK, MINW>), dim3(grid), dim3(BLOCK), lds_bytes, a.stream, a.rg2.desc,    \
+                     a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, a.rg2.n_wg, nl, \
+                     acc_doubles)
+    if (a.opt_occ == 1) RDC_RG4(1); else RDC_RG4(2);
+#undef RDC_RG4
+    return hipGetLastError();
+  }
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.opt_kernel == 0) {
 #define RDC_RG3(BLOCK, MINW)                                                                                       \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
