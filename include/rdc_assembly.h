@@ -208,6 +208,11 @@ int rdc_timing_last_ms(rdc_ctx* ctx, float* ms);
  * synchronises on the recorded events and resets the pool (no host sync happens inside assemble) */
 int rdc_timing_sum_ms(rdc_ctx* ctx, float* total_ms, int* n_calls);
 
+/* diagnostic only: call with host_out == NULL to arm (the next shipped-parameter PIHNA/TET4 assembly then
+ * runs a separately compiled kernel that records s_memtime stamps per workgroup phase; *n_written = number
+ * of values), call again with a buffer to fetch them: [workgroup][wave][6] shader-clock stamps. */
+int rdc_debug_stamps(rdc_ctx* ctx, long long* host_out, int64_t capacity, int64_t* n_written);
+
 #ifdef __cplusplus
 }
 #endif

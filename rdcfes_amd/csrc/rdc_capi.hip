@@ -41,6 +41,7 @@ struct rdc_ctx {
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
       wg_node_ptr;
   DevBuf val, rhs, packed;
+  DevBuf stamps;
   DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab, rg4_nlist, rg4_ploc;
   DevBuf field[RDC_FIELD_COUNT];
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
@@ -205,6 +206,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_special = c->opt_special;
   a.opt_xcd = c->opt_xcd;
   a.opt_grid = c->opt_grid;
+  a.stamps = (long long*)c->stamps.p;
   if (c->prep.rg2_ok && c->prep.nen == 4) {
     a.rg2.n_wg = (int)c->prep.wg2.size();
     a.rg2.desc = (const HostPrep::WgDesc*)c->rg2_desc.p;
@@ -278,7 +280,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
-                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
+                   &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
   for (DevBuf* b : all) dev_free(c, *b);
@@ -329,7 +331,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
   else if (!std::strcmp(key, "grid")) c->opt_grid = value;
-  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = flat-list LDS row gather, 1 = first row-gather kernel, 2 = staged (deterministic) row gather
+  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = default (LDS-staged node records, k_tet4_rg5), 3 = k_tet4_rg3, 4 = persistent k_tet4_rg4,
+                                                                 // 1 = first row-gather kernel, 2 = staged deterministic k_tet4_rg2
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;
 }
@@ -632,6 +635,27 @@ int rdc_clamp_nonnegative(rdc_ctx* c, int field) {
     hipLaunchKernelGGL(k_clamp_nonnegative, dim3((unsigned)grid), dim3(256), 0, c->stream, (double*)c->field[field].p, n);
     RDC_HIP(c, hipGetLastError());
   }
+  return RDC_OK;
+}
+
+int rdc_debug_stamps(rdc_ctx* c, long long* host_out, int64_t capacity, int64_t* n_written) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh || !c->prep.rg2_ok) return fail(c, RDC_ERR_STATE, "no row-gather work lists");
+  int rc = set_device(c);
+  if (rc) return rc;
+  const int64_t n = (int64_t)c->prep.wg2.size() * 4 * 6;
+  if (!host_out) {  // arm: the next PIHNA (shipped-parameter) assembly runs the stamped diagnostic kernel
+    if ((rc = dev_alloc(c, c->stamps, (size_t)n * sizeof(long long)))) return rc;
+    RDC_HIP(c, hipMemsetAsync(c->stamps.p, 0, (size_t)n * sizeof(long long), c->stream));
+    if (n_written) *n_written = n;
+    return RDC_OK;
+  }
+  if (!c->stamps.p) return fail(c, RDC_ERR_STATE, "stamps not armed");
+  const int64_t m = n < capacity ? n : capacity;
+  RDC_HIP(c, hipMemcpyAsync(host_out, c->stamps.p, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  if (n_written) *n_written = m;
+  dev_free(c, c->stamps);
   return RDC_OK;
 }
 

@@ -40,6 +40,7 @@ struct LaunchArgs {
   int variant;     // RDC_VARIANT_*
   int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
+  long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;
   double* rhs;
   hipStream_t stream;

@@ -166,13 +166,18 @@ struct LdsSink3 {
   }
 };
 
-template <class M, int EXP_MODE, int BLOCK, int MINW>
+template <class M, int EXP_MODE, int BLOCK, int MINW, bool STAMP = false>
 __global__ void __launch_bounds__(BLOCK, MINW)
 k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_rec,
            const uint16_t* __restrict__ pair_aux, const uint16_t* __restrict__ node_tab, const typename M::K k,
-           const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int xcd_remap) {
+           const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int xcd_remap,
+           long long* __restrict__ stamps) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
+  constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC;
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ uint2 ntab[MAXN];  // node_tab entries of the workgroup's nodes (used in the fold phase)
+  long long ts[6];
+  if (STAMP) ts[0] = __builtin_amdgcn_s_memtime();
   // workgroups are dealt round-robin to the 8 XCDs (observed, used for speed only): give each XCD a
   // contiguous range of the node ordering so neighbouring workgroups share node records in ONE L2
   // (bijection for any grid size: XCD x owns q + (x < r) consecutive workgroups)
@@ -194,11 +199,12 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     load_rec<M>(rec, pr.z, X[2], U[2], AX[2]);
     load_rec<M>(rec, pr.w, X[3], U[3], AX[3]);
   }
+  if ((int)threadIdx.x < d.nnodes) ntab[threadIdx.x] = reinterpret_cast<const uint2*>(node_tab)[d.n0 + threadIdx.x];
   // zero the accumulators while the loads are in flight: [row slice | private diagonals]
-  constexpr int ns = HostPrep::RG3_DIAG_SLOTS;
   const int nval = d.nb * NV * NV, ntot = nval + NDV * ns;
   for (int x = threadIdx.x; x < ntot; x += BLOCK) lds[x] = 0.0;
   __syncthreads();
+  if (STAMP) ts[1] = __builtin_amdgcn_s_memtime();
   if (valid) {
     LdsSink3<M> sink;
     sink.row = lds + (ax.x & 0xFFFF);
@@ -209,7 +215,9 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
     tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
   }
+  if (STAMP) ts[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
+  if (STAMP) ts[3] = __builtin_amdgcn_s_memtime();
   // fold the private copies: diagonal block values into the row slice, rhs straight to memory
   for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
     const int v = x / d.nnodes, n = x - v * d.nnodes;  // consecutive threads -> consecutive nodes (stride NC doubles)
@@ -218,7 +226,7 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
 #pragma unroll
     for (int c = 0; c < NC; c++) sum += src[c];
     if (v < NV * NV) {
-      const uint2 nt = reinterpret_cast<const uint2*>(node_tab)[d.n0 + n];  // {rowoff | stride << 16, diagoff}
+      const uint2 nt = ntab[n];  // {rowoff | stride << 16, diagoff}
       const int a = v / NV, b = v - a * NV;
       lds[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + b] = sum;  // nothing else writes the diagonal
     } else {
@@ -226,8 +234,122 @@ k_tet4_rg3(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     }
   }
   __syncthreads();
+  if (STAMP) ts[4] = __builtin_amdgcn_s_memtime();
   double* out = val + d.vb0;
   for (int x = threadIdx.x; x < nval; x += BLOCK) __builtin_nontemporal_store(lds[x], out + x);
+  if (STAMP) {
+    ts[5] = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0 && stamps) {
+      long long* o = stamps + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 6;
+#pragma unroll
+      for (int x = 0; x < 6; x++) o[x] = ts[x];
+    }
+  }
+}
+
+// ---- row gather with LDS-staged node records (default) ------------------------------------------
+// In-kernel stamps of k_tet4_rg3 (tools/stamp_report.py) put 38% of a wave's lifetime into the initial
+// load phase: 256 pairs x 4 nodes x 4 pieces = 4,096 scattered 16-byte requests per workgroup through
+// the L1/TA, for only ~84 distinct node records.  Here wave r gathers list entries [64r, 64r+64) of the
+// workgroup's node list straight into LDS (LDS-DMA, no VGPRs: ~340 requests), and the pairs read their
+// four records from LDS through 8-bit list indices.  Everything after that is k_tet4_rg3.
+template <class M, int EXP_MODE, int BLOCK, int MINW, bool STAMP = false>
+__global__ void __launch_bounds__(BLOCK, MINW)
+k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_loc,
+           const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
+           const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
+           double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
+           long long* __restrict__ stamps) {
+  constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
+  constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
+  __shared__ uint2 ntab[MAXN];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  long long ts[6];
+  if (STAMP) ts[0] = __builtin_amdgcn_s_memtime();
+  const int w = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = lane * NW + wv;
+  double* const recs = lds + acc_doubles;
+  // level 1 (independent): node ids of this wave's round, pair record, descriptor
+  const int rounds = nl_stride >> 6;
+  uint32_t nid = 0;
+  if (wv < rounds) nid = nlist[(size_t)w * nl_stride + wv * 64 + lane];
+  const uint32_t pl = pair_loc[(size_t)w * BLOCK + idx];
+  const uint4 ax = reinterpret_cast<const uint4*>(pair_aux)[(size_t)w * BLOCK + idx];
+  const HostPrep::WgDesc d = desc[w];
+  // level 2: gather the distinct node records into LDS
+  if (wv < rounds) {
+    const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(recs + (p * nl_stride + wv * 64) * 2), 16, 0, 0);
+  }
+  if ((int)threadIdx.x < d.nnodes) ntab[threadIdx.x] = reinterpret_cast<const uint2*>(node_tab)[d.n0 + threadIdx.x];
+  const int nval = d.nb * NV * NV, ntot = nval + NDV * ns;
+  for (int x = threadIdx.x; x < ntot; x += BLOCK) lds[x] = 0.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed ...
+  __syncthreads();                                   // ... and so has everybody else's
+  if (STAMP) ts[1] = __builtin_amdgcn_s_memtime();
+  if (pl != 0xFFFFFFFFu) {
+    double X[4][3], U[4][NV], AX[4][M::NAUX > 0 ? M::NAUX : 1];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int li = (pl >> (8 * j)) & 0xFF;
+      double r[2 * NP];
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        const double2 v2 = reinterpret_cast<const double2*>(recs)[p * nl_stride + li];
+        r[2 * p] = v2.x; r[2 * p + 1] = v2.y;
+      }
+      X[j][0] = r[0]; X[j][1] = r[1]; X[j][2] = r[2];
+#pragma unroll
+      for (int v = 0; v < NV; v++) U[j][v] = r[3 + v];
+      if (M::NAUX > 0) {
+#pragma unroll
+        for (int v = 0; v < M::NAUX; v++) AX[j][v] = r[3 + NV + v];
+      } else {
+        AX[j][0] = 0.0;
+      }
+    }
+    LdsSink3<M> sink;
+    sink.row = lds + (ax.x & 0xFFFF);
+    sink.stride = (int)(ax.x >> 16);
+    sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
+    sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
+    sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
+    tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
+  }
+  if (STAMP) ts[2] = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+  if (STAMP) ts[3] = __builtin_amdgcn_s_memtime();
+  for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
+    const int v = x / d.nnodes, n = x - v * d.nnodes;
+    const double* src = lds + nval + v * ns + n * NC;
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) sum += src[c];
+    if (v < NV * NV) {
+      const uint2 nt = ntab[n];
+      const int a = v / NV, b = v - a * NV;
+      lds[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + b] = sum;
+    } else {
+      rhs[(int64_t)(d.n0 + n) * NV + (v - NV * NV)] = sum;
+    }
+  }
+  __syncthreads();
+  if (STAMP) ts[4] = __builtin_amdgcn_s_memtime();
+  double* out = val + d.vb0;
+  for (int x = threadIdx.x; x < nval; x += BLOCK) __builtin_nontemporal_store(lds[x], out + x);
+  if (STAMP) {
+    ts[5] = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0 && stamps) {
+      long long* o = stamps + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 6;
+#pragma unroll
+      for (int x = 0; x < 6; x++) o[x] = ts[x];
+    }
+  }
 }
 
 // ---- persistent, software-pipelined row gather -----------------------------------------------
@@ -529,10 +651,34 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG4
     return hipGetLastError();
   }
-  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.opt_kernel == 0) {
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
+      a.opt_kernel == 0) {
+    constexpr int BLOCK = 256;
+    const int nl = a.rg2.nl_stride;
+    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
+    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + (size_t)(Rec<M>::N / 2) * nl * 2);
+#define RDC_RG5(MINW, ST)                                                                                          \
+  hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,     \
+                     a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
+                     nl, acc_doubles, a.stamps)
+    if (a.stamps && std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) RDC_RG5(2, true);
+    else if (a.opt_occ == 1) RDC_RG5(1, false);
+    else RDC_RG5(2, false);
+#undef RDC_RG5
+    return hipGetLastError();
+  }
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && (a.opt_kernel == 0 || a.opt_kernel == 3)) {
 #define RDC_RG3(BLOCK, MINW)                                                                                       \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
-                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs, a.opt_xcd)
+                     a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs, a.opt_xcd,  \
+                     (long long*)nullptr)
+    if (a.stamps && a.rg2.block == 256 && std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) {
+      // diagnostic build with s_memtime stamps per phase (tools/stamp_report.py); never the timed kernel
+      hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, 256, 2, true>), dim3(a.rg2.n_wg), dim3(256), a.rg2.lds_bytes, a.stream,
+                         a.rg2.desc, a.rg2.pair_rec, a.rg2.pair_aux, a.rg2.node_tab, k, a.packed, a.val, a.rhs, a.opt_xcd,
+                         a.stamps);
+      return hipGetLastError();
+    }
     if (a.rg2.block == 128) {  // MINW counts waves per SIMD: 2 means four 128-thread workgroups per CU
       if (a.opt_occ == 1) RDC_RG3(128, 1); else RDC_RG3(128, 2);
     } else {
