@@ -32,6 +32,7 @@ struct rdc_ctx {
   int variant = RDC_VARIANT_AUTO;
   int opt_occ = 2, opt_ablate = 0, opt_kernel = 0;
   int opt_xcd = 0;      // XCD-aware workgroup order of the row-gather kernel (measured: no gain, off)
+  int opt_pf = 0;       // L2 prefetch distance (workgroups) of the work lists in k_tet4_rg5; 0 = off
   int opt_grid = 0;     // persistent grid size of the pipelined kernel (0 = 2 workgroups per CU)
   int opt_sched = 1;    // LDS-conflict-aware pair schedule (takes effect at the next rdc_mesh_upload)
   int opt_special = 1;  // allow parameter-sparsity kernel variants
@@ -206,6 +207,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_special = c->opt_special;
   a.opt_xcd = c->opt_xcd;
   a.opt_grid = c->opt_grid;
+  a.opt_pf = c->opt_pf;
   a.stamps = (long long*)c->stamps.p;
   if (c->prep.rg2_ok && c->prep.nen == 4) {
     a.rg2.n_wg = (int)c->prep.wg2.size();
@@ -331,6 +333,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
   else if (!std::strcmp(key, "grid")) c->opt_grid = value;
+  else if (!std::strcmp(key, "prefetch")) c->opt_pf = value;
   else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = default (LDS-staged node records, k_tet4_rg5), 3 = k_tet4_rg3, 4 = persistent k_tet4_rg4,
                                                                  // 1 = first row-gather kernel, 2 = staged deterministic k_tet4_rg2
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
@@ -643,7 +646,7 @@ int rdc_debug_stamps(rdc_ctx* c, long long* host_out, int64_t capacity, int64_t*
   if (!c->have_mesh || !c->prep.rg2_ok) return fail(c, RDC_ERR_STATE, "no row-gather work lists");
   int rc = set_device(c);
   if (rc) return rc;
-  const int64_t n = (int64_t)c->prep.wg2.size() * 4 * 6;
+  const int64_t n = (int64_t)c->prep.wg2.size() * 4 * 9;
   if (!host_out) {  // arm: the next PIHNA (shipped-parameter) assembly runs the stamped diagnostic kernel
     if ((rc = dev_alloc(c, c->stamps, (size_t)n * sizeof(long long)))) return rc;
     RDC_HIP(c, hipMemsetAsync(c->stamps.p, 0, (size_t)n * sizeof(long long), c->stream));

@@ -38,7 +38,7 @@ struct LaunchArgs {
   const double* aux;
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
-  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid;  // tuning knobs (rdc_set_option)
+  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;

@@ -259,14 +259,14 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
            const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
            const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
-           long long* __restrict__ stamps) {
+           long long* __restrict__ stamps, const int pf_dist) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
   __shared__ uint2 ntab[MAXN];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-  long long ts[6];
+  long long ts[6], tx[3] = {0, 0, 0};
   if (STAMP) ts[0] = __builtin_amdgcn_s_memtime();
   const int w = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -279,6 +279,23 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   const uint32_t pl = pair_loc[(size_t)w * BLOCK + idx];
   const uint4 ax = reinterpret_cast<const uint4*>(pair_aux)[(size_t)w * BLOCK + idx];
   const HostPrep::WgDesc d = desc[w];
+  // The work lists are read exactly once, so the level-1 loads above are HBM misses.  Touch the lists of
+  // the workgroup that will run pf_dist dispatch slots later on this XCD (workgroups are dealt round-robin
+  // over the 8 XCDs; pf_dist is a multiple of 8): by then they are L2 hits.  Fire-and-forget loads whose
+  // results are never used -- written in asm so that no wait is generated for them.  Speed only.
+  if (pf_dist > 0 && w + pf_dist < (int)gridDim.x) {
+    const size_t wp = (size_t)(w + pf_dist);
+    unsigned t0, t1, t2;
+    const void* p0 = pair_loc + wp * BLOCK + threadIdx.x;
+    const void* p1 = reinterpret_cast<const uint4*>(pair_aux) + wp * BLOCK + threadIdx.x;
+    const void* p2 = nlist + wp * nl_stride + (threadIdx.x < (unsigned)nl_stride ? threadIdx.x : 0);
+    asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+  }
+  if (STAMP) {  // diagnostic only: serialise the levels to time them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    tx[0] = __builtin_amdgcn_s_memtime();
+  }
   // level 2: gather the distinct node records into LDS
   if (wv < rounds) {
     const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
@@ -288,8 +305,10 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   }
   if ((int)threadIdx.x < d.nnodes) ntab[threadIdx.x] = reinterpret_cast<const uint2*>(node_tab)[d.n0 + threadIdx.x];
   const int nval = d.nb * NV * NV, ntot = nval + NDV * ns;
+  if (STAMP) tx[1] = __builtin_amdgcn_s_memtime();
   for (int x = threadIdx.x; x < ntot; x += BLOCK) lds[x] = 0.0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed ...
+  if (STAMP) tx[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();                                   // ... and so has everybody else's
   if (STAMP) ts[1] = __builtin_amdgcn_s_memtime();
   if (pl != 0xFFFFFFFFu) {
@@ -348,6 +367,10 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
       long long* o = stamps + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 6;
 #pragma unroll
       for (int x = 0; x < 6; x++) o[x] = ts[x];
+      // sub-stamps of phase 0 go behind the main table
+      long long* o2 = stamps + (int64_t)gridDim.x * NW * 6 + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 3;
+#pragma unroll
+      for (int x = 0; x < 3; x++) o2[x] = tx[x] - ts[0];
     }
   }
 }
@@ -371,9 +394,9 @@ k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   extern __shared__ __attribute__((aligned(16))) double lds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-  // LDS map: [accumulators: row slice | private diagonals] [2 x (records | pair_aux | pair_loc)]
+  // LDS map: [accumulators: row slice | private diagonals] [2 x (records | pair_aux | pair_loc | descriptor)]
   const int rec_doubles = NP * nl_stride * 2;
-  const int buf_doubles = rec_doubles + BLOCK * 2 + BLOCK / 2;
+  const int buf_doubles = rec_doubles + BLOCK * 2 + BLOCK / 2 + 8;
   double* const bufs = lds + acc_doubles;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = lane * NW + wv;  // pair slot of this thread (see k_tet4_rg3)
@@ -393,6 +416,10 @@ k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     __builtin_amdgcn_global_load_lds((glb_ptr)ax, (lds_ptr)(base + rec_doubles + wv * 128), 16, 0, 0);
     const char* pl = reinterpret_cast<const char*>(pair_loc) + ((size_t)item * BLOCK + threadIdx.x) * 4;
     __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(base + rec_doubles + BLOCK * 2 + wv * 32), 4, 0, 0);
+    if (threadIdx.x < 4) {  // the 64-byte workgroup descriptor, too: a scalar load at the top of the item would expose a full memory latency
+      const char* dd = reinterpret_cast<const char*>(desc + item) + threadIdx.x * 16;
+      __builtin_amdgcn_global_load_lds((glb_ptr)dd, (lds_ptr)(base + rec_doubles + BLOCK * 2 + BLOCK / 2), 16, 0, 0);
+    }
   };
 
   int w = blockIdx.x;
@@ -409,7 +436,7 @@ k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   }
   for (int it = 0; w < nwg; it++, w += G) {
     const int b = it & 1;
-    const HostPrep::WgDesc d = desc[w];
+    const HostPrep::WgDesc d = *reinterpret_cast<const HostPrep::WgDesc*>(bufs + b * buf_doubles + rec_doubles + BLOCK * 2 + BLOCK / 2);
     const int wn = w + G;
     uint32_t nid_n2 = 0;
     if (wn < nwg) {  // buffer b^1 was last read before the barriers that ended the previous iteration
@@ -640,7 +667,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     constexpr int BLOCK = 256;
     const int nl = a.rg2.nl_stride;
     const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
-    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + 2 * ((size_t)(Rec<M>::N / 2) * nl * 2 + BLOCK * 2 + BLOCK / 2));
+    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + 2 * ((size_t)(Rec<M>::N / 2) * nl * 2 + BLOCK * 2 + BLOCK / 2 + 8));
     int grid = a.opt_grid > 0 ? a.opt_grid : 512;
     if (grid > a.rg2.n_wg) grid = a.rg2.n_wg;
 #define RDC_RG4(MINW)                                                                                              \
@@ -660,7 +687,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #define RDC_RG5(MINW, ST)                                                                                          \
   hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,     \
                      a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
-                     nl, acc_doubles, a.stamps)
+                     nl, acc_doubles, a.stamps, a.opt_pf)
     if (a.stamps && std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) RDC_RG5(2, true);
     else if (a.opt_occ == 1) RDC_RG5(1, false);
     else RDC_RG5(2, false);

@@ -18,7 +18,9 @@ ctx._ck(ctx._lib.rdc_debug_stamps(ctx._h, None, 0, C.byref(nw)))
 ctx.assemble_pihna(p); ctx.synchronize()
 buf = np.zeros(nw.value, dtype=np.int64)
 ctx._ck(ctx._lib.rdc_debug_stamps(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size, C.byref(nw)))
-t = buf.reshape(-1, 4, 6).astype(np.float64)
+nwg = buf.size // 36
+t = buf[:nwg * 24].reshape(-1, 4, 6).astype(np.float64)
+sub = buf[nwg * 24:].reshape(-1, 4, 3).astype(np.float64)
 d = np.diff(t, axis=2)  # [wg][wave][5 phases]
 names = ["loads+zero+barrier", "compute (prepare+rows+atomics issue)", "wait at barrier (LDS drain, slowest wave)", "fold + barrier", "flush stores issue"]
 tot = (t[:, :, 5] - t[:, :, 0])
@@ -27,3 +29,5 @@ for i, nm in enumerate(names):
     print(f"{nm:45s} median {np.median(d[:, :, i]):8.0f}  mean {d[:, :, i].mean():8.0f}  share {d[:, :, i].sum() / tot.sum():6.1%}")
 span = t[:, :, 5].max() - t[:, :, 0].min()
 print("kernel span (ticks):", span)
+print("phase 0 detail (cycles since wave start): level-1 loads back", np.median(sub[:, :, 0]), " DMA issued + ntab", np.median(sub[:, :, 1]),
+      " zero done + DMA landed", np.median(sub[:, :, 2]), " (waves with a DMA round:", np.median(sub[:, :2, 2]), " others:", np.median(sub[:, 2:, 2]), ")")
