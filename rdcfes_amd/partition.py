@@ -33,9 +33,25 @@ def partition_rcb(centroids: np.ndarray, nparts: int) -> np.ndarray:
         c = centroids[idx]
         ax = int(np.argmax(c.max(axis=0) - c.min(axis=0))) if idx.size else 0
         nl = (idx.size * kl) // k
-        order = np.argsort(c[:, ax], kind="stable")
-        todo.append((idx[order[:nl]], base, kl))
-        todo.append((idx[order[nl:]], base + kl, k - kl))
+        # O(n) selection instead of a full sort; ties are broken by element id so that every rank
+        # computes the same partition
+        key = c[:, ax]
+        if 0 < nl < idx.size:
+            order = np.argpartition(key, nl - 1)
+            left, right = order[:nl], order[nl:]
+            # make the split deterministic w.r.t. equal keys: elements equal to the pivot go by index
+            pivot = key[left].max()
+            eq = np.nonzero(key == pivot)[0]
+            if eq.size > 1:
+                n_left_strict = int((key < pivot).sum())
+                take = np.sort(eq)[: nl - n_left_strict]
+                mask = key < pivot
+                mask[take] = True
+                left, right = np.nonzero(mask)[0], np.nonzero(~mask)[0]
+        else:
+            left, right = np.arange(nl), np.arange(nl, idx.size)
+        todo.append((idx[left], base, kl))
+        todo.append((idx[right], base + kl, k - kl))
     return part
 
 
