@@ -259,7 +259,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
            const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
            const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
-           long long* __restrict__ stamps, const int pf_dist) {
+           long long* __restrict__ stamps, const int pf_dist, const int xcd_remap) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
@@ -268,7 +268,11 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   long long ts[6], tx[3] = {0, 0, 0};
   if (STAMP) ts[0] = __builtin_amdgcn_s_memtime();
-  const int w = blockIdx.x;
+  int w = blockIdx.x;
+  if (xcd_remap) {  // contiguous range of work items per XCD (see k_tet4_rg3); speed only
+    const int q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
+    w = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = lane * NW + wv;
   double* const recs = lds + acc_doubles;
@@ -687,7 +691,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #define RDC_RG5(MINW, ST)                                                                                          \
   hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,     \
                      a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
-                     nl, acc_doubles, a.stamps, a.opt_pf)
+                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd)
     if (a.stamps && std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) RDC_RG5(2, true);
     else if (a.opt_occ == 1) RDC_RG5(1, false);
     else RDC_RG5(2, false);

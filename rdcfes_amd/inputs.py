@@ -1,0 +1,89 @@
+"""`input.dat` (GetPot `key = value`) → the parameter structs of the solid path, with the lookup
+semantics of the reference's `input()` (`src/solid.C:139-281`): a key that is absent falls back to the
+default coded there, whatever similar-looking key the file holds (the shipped files
+spell `material/<m>/Neohookean/*` and `solver/use_symmetry`, neither of which is read)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .params import SolidMaterial, SolidParams
+
+
+def parse_getpot(text: str) -> dict:
+    """Flat `name = value` subset of GetPot: `#` comments, quoted strings, no sections/includes."""
+    out = {}
+    for raw in text.splitlines():
+        ln = raw.split("#", 1)[0].strip()
+        if "=" not in ln:
+            continue
+        k, v = ln.split("=", 1)
+        v = v.strip()
+        if len(v) >= 2 and v[0] == v[-1] and v[0] in "'\"":
+            v = v[1:-1]
+        out[k.strip()] = v
+    return out
+
+
+def _real(kv, name, default):
+    if name not in kv:
+        return default
+    s = kv[name].strip().lower()
+    return math.nan if s.lstrip("+-") == "nan" else float(s)
+
+
+def _bool(kv, name, default):
+    return kv[name].strip().lower() in ("true", "1") if name in kv else default
+
+
+def _ints(s):  # export_integers(), src/utils.C
+    return sorted({int(t) for t in s.split()})
+
+
+class SolidSetup:
+    """What `SolidSystem` reads from `es.parameters` on the assembly path."""
+
+    def __init__(self, kv: dict):
+        self.loading_step = _real(kv, "loading_step", 0.1)                      # src/solid.C:151
+        self.n_load_steps = int(1.0 / self.loading_step)                        # src/solid.C:154
+        self.use_symmetry = _bool(kv, "solver/assembly_use_symmetry", False)    # src/solid.C:236
+        self.penalty = _real(kv, "BCs/displacement_penalty", 1.0e5)             # src/solid.C:258
+        self.bcs = {bc: tuple(_real(kv, f"BC/{bc}/displacement/{d}", 0.0) for d in range(3))
+                    for bc in _ints(kv.get("BCs", " 0 "))}                      # src/solid.C:240-256
+        self.materials = {}
+        for m in _ints(kv.get("materials", " 0 ")):                             # src/solid.C:262-279
+            h = f"material/{m}/Hyperelastic/"
+            self.materials[m] = SolidMaterial(
+                _real(kv, h + "Young", 1.0e3), _real(kv, h + "Poisson", 0.3), _real(kv, h + "FibreStiffness", 0.0),
+                tuple(_real(kv, h + f"VolumetricStretchRatio/rate_{d}", 0.0) for d in range(3)))
+
+    def params(self, pseudo_time: float) -> SolidParams:
+        return SolidParams(pseudo_time, self.penalty, int(self.use_symmetry), 0)
+
+    def material_table(self, subdomain: np.ndarray):
+        """(elem_material index array, materials list) for `rdc_solid_set_materials`; a subdomain id the
+        input does not list is the reference's `parameters.get` abort (src/solid_system.C:184)."""
+        ids = sorted(self.materials)
+        lut = {m: i for i, m in enumerate(ids)}
+        missing = set(np.unique(subdomain).tolist()) - set(ids)
+        if missing:
+            raise KeyError(f"no material/<m>/Hyperelastic entry for subdomain ids {sorted(missing)}")
+        return np.array([lut[int(s)] for s in subdomain], dtype=np.int32), [self.materials[m] for m in ids]
+
+    def sides(self, mesh):
+        """(elem, side, displacement[3]) of every side carrying a listed boundary id, in ascending id order
+        (`for (auto bc : BCs_set)`, src/solid_system.C:294-306).  A side with two listed ids appears twice,
+        as in the reference."""
+        es, ss, sd = [], [], []
+        for bc, disp in sorted(self.bcs.items()):
+            e, s = mesh.sides_with_boundary_id(bc)
+            es.append(e); ss.append(s); sd.append(np.tile(np.asarray(disp, dtype=np.float64), (e.size, 1)))
+        if not es:
+            return np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros((0, 3))
+        return np.concatenate(es), np.concatenate(ss), np.concatenate(sd)
+
+
+def read_solid_input(path) -> SolidSetup:
+    with open(path) as fh:
+        return SolidSetup(parse_getpot(fh.read()))
