@@ -40,8 +40,7 @@ def oracle():
     return O
 
 
-@pytest.fixture(scope="session")
-def shim():
+def build_shim():
     """g++ build of the product's host/device headers (tests/host_shim.cpp)."""
     bdir = ROOT / "tests" / "_build"
     bdir.mkdir(exist_ok=True)
@@ -57,6 +56,11 @@ def shim():
     lib.shim_prep_size.argtypes = [C.c_int]
     lib.shim_prep_error.restype = C.c_char_p
     return lib
+
+
+@pytest.fixture(scope="session")
+def shim():
+    return build_shim()
 
 
 class Prep:
