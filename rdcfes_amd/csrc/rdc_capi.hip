@@ -48,6 +48,9 @@ struct rdc_ctx {
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
   // solid
   DevBuf elem_material, materials, side_elem, side_id, side_disp;
+  DevBuf solid_ke, solid_fe, sg_gptr, sg_gsrc, sg_brow;  // two-pass assembly: element matrices + gather lists
+  bool solid_gather_ready = false;
+  int opt_solid_kernel = 0;  // 0 = two-pass (default), 1 = coloured read-modify-write
   int32_t n_materials = 0;
   int64_t n_sides = 0;
   // timing
@@ -284,7 +287,8 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc,
-                   &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp};
+                   &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
+                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -334,6 +338,10 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
   else if (!std::strcmp(key, "grid")) c->opt_grid = value;
   else if (!std::strcmp(key, "prefetch")) c->opt_pf = value;
+  else if (!std::strcmp(key, "solid_kernel")) {
+    if (value != 0 && value != 1) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (two-pass) or 1 (coloured)");
+    c->opt_solid_kernel = value;
+  }
   else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = default (LDS-staged node records, k_tet4_rg5), 3 = k_tet4_rg3, 4 = persistent k_tet4_rg4,
                                                                  // 1 = first row-gather kernel, 2 = staged deterministic k_tet4_rg2
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
@@ -399,6 +407,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   dev_free(c, c->side_elem); dev_free(c, c->side_id); dev_free(c, c->side_disp);
   c->n_materials = 0; c->n_sides = 0;
   c->have_mesh = true;
+  c->solid_gather_ready = false;
   return RDC_OK;
 }
 
@@ -595,6 +604,32 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   a.stream = c->stream;
   a.colour_ptr = c->prep.colour_ptr.data();
   a.n_colours = c->prep.n_colours;
+  a.kernel = c->opt_solid_kernel;
+  a.nblocks = c->prep.bptr[(size_t)c->prep.n_owned];
+  if (a.kernel == 0) {
+    if (!c->solid_gather_ready) {  // one-time: gather lists and the element-matrix buffers
+      SolidGather g;
+      const std::string err = solid_gather_build(c->prep, g);
+      if (!err.empty()) return fail(c, RDC_ERR_UNSUPPORTED, "%s", err.c_str());
+      if ((rc = dev_upload(c, c->sg_gptr, g.gptr))) return rc;
+      if ((rc = dev_upload(c, c->sg_gsrc, g.gsrc))) return rc;
+      if ((rc = dev_upload(c, c->sg_brow, g.brow))) return rc;
+      const size_t rows = (size_t)c->prep.n_elem * c->prep.nen;
+      if ((rc = dev_alloc(c, c->solid_ke, rows * c->prep.nen * 9 * sizeof(double)))) return rc;
+      if ((rc = dev_alloc(c, c->solid_fe, rows * 3 * sizeof(double)))) return rc;
+      RDC_HIP(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+      c->solid_gather_ready = true;
+    }
+    a.ke = (double*)c->solid_ke.p;
+    a.fe = (double*)c->solid_fe.p;
+    a.gptr = (const uint32_t*)c->sg_gptr.p;
+    a.gsrc = (const uint32_t*)c->sg_gsrc.p;
+    a.brow = (const int32_t*)c->sg_brow.p;
+  } else {
+    a.ke = a.fe = nullptr;
+    a.gptr = a.gsrc = nullptr;
+    a.brow = nullptr;
+  }
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   if (c->timing) {
     if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;

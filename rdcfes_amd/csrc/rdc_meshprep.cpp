@@ -452,4 +452,35 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
   return std::string();
 }
 
+std::string solid_gather_build(const HostPrep& P, SolidGather& G) {
+  const int nen = P.nen;
+  const int64_t nb = P.bptr.empty() ? 0 : P.bptr[(size_t)P.n_owned];
+  const int64_t npairs = P.node_pair_ptr.empty() ? 0 : P.node_pair_ptr[(size_t)P.n_owned];
+  if ((uint64_t)P.n_elem * nen * nen >= 0xFFFFFFFFull || (uint64_t)npairs * nen >= 0xFFFFFFFFull)
+    return "mesh too large for 32-bit gather lists";
+  G.gptr.assign((size_t)nb + 1, 0);
+  G.brow.resize((size_t)nb);
+  G.gsrc.resize((size_t)npairs * nen);
+#pragma omp parallel for schedule(static)
+  for (int64_t I = 0; I < P.n_owned; I++) {
+    for (int64_t b = P.bptr[I]; b < P.bptr[I + 1]; b++) G.brow[(size_t)b] = (int32_t)I;
+    for (int64_t p = P.node_pair_ptr[I]; p < P.node_pair_ptr[I + 1]; p++) {
+      const uint16_t* es = &P.eslot[((size_t)P.pair_elem[p] * nen + P.pair_local[p]) * nen];
+      for (int j = 0; j < nen; j++) G.gptr[(size_t)(P.bptr[I] + es[j]) + 1]++;
+    }
+  }
+  for (int64_t b = 0; b < nb; b++) G.gptr[(size_t)b + 1] += G.gptr[(size_t)b];
+#pragma omp parallel for schedule(static)
+  for (int64_t I = 0; I < P.n_owned; I++) {
+    const int64_t b0 = P.bptr[I], len = P.bptr[I + 1] - b0;
+    std::vector<uint32_t> fill((size_t)len, 0);
+    for (int64_t p = P.node_pair_ptr[I]; p < P.node_pair_ptr[I + 1]; p++) {
+      const uint32_t base = (P.pair_elem[p] * (uint32_t)nen + P.pair_local[p]) * (uint32_t)nen;
+      const uint16_t* es = &P.eslot[(size_t)base];
+      for (int j = 0; j < nen; j++) G.gsrc[(size_t)G.gptr[(size_t)(b0 + es[j])] + fill[es[j]]++] = base + (uint32_t)j;
+    }
+  }
+  return std::string();
+}
+
 }  // namespace rdc

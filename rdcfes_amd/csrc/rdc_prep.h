@@ -82,6 +82,15 @@ struct HostPrep {
   std::vector<uint16_t> contrib;    // stage index (doubles) of the contribution: pair * stride + slot(column), see rdc_meshprep.cpp
 };
 
+// Gather lists of the two-pass solid assembly (rdc_solid.hip): for every node block b of the owned rows the
+// element-matrix blocks (e, i, j) that sum into it, as src = (e * nen + i) * nen + j, in ascending
+// (element, local row) order => a fixed summation order.  gptr has bptr[n_owned] + 1 entries.
+struct SolidGather {
+  std::vector<uint32_t> gptr, gsrc;
+  std::vector<int32_t> brow;   // owner node of block b
+};
+std::string solid_gather_build(const HostPrep& P, SolidGather& out);
+
 // returns empty string on success, else an error message
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,
                        int nvar, size_t lds_budget_bytes, int block, HostPrep& out, bool conflict_aware = true);

@@ -21,6 +21,13 @@ struct SolidArgs {
   hipStream_t stream;
   const int64_t* colour_ptr;   // host
   int n_colours;
+  int kernel;                  // 0 = two-pass (element matrices + gather), 1 = coloured read-modify-write
+  double* ke;                  // [n_elem][nen][nen][3][3] element matrices (two-pass)
+  double* fe;                  // [n_elem][nen][3]
+  int64_t nblocks;             // node blocks of the owned rows
+  const uint32_t* gptr;
+  const uint32_t* gsrc;
+  const int32_t* brow;
 };
 hipError_t launch_solid(const SolidArgs& a);
 }  // namespace rdc

@@ -305,7 +305,330 @@ __global__ void k_solid_sides(const MeshDev m, int64_t n_sides, const int64_t* _
   }
 }
 
+// ================================================================================================
+// Two-pass assembly (default).  The solid tangent is FP64-compute-bound (~26 k FMA per HEX8 element
+// after the algebra below, against ~5 kB of compulsory traffic), so the scatter is taken off the
+// compute kernel altogether:
+//   pass 1  k_solid_elem   every element once: its NEN x NEN blocks of 3x3 -> ke[e][i][j][3][3], fe[e][i][3]
+//   pass 2  k_solid_gather every CSR node block once: sum of the element blocks listed for it
+//           (SolidGather, fixed order => deterministic), written to its three row pieces.
+// No atomics, no colours, no recomputation; the price is one write + one read of the element
+// matrices (4.6 kB per HEX8) through HBM, which costs less than the constitutive work it saves.
+//
+// Element-matrix algebra.  With c_ijkl and sigma from the header comment, and the B-matrices of
+// hyperlastic_inline.h:3-15, the block of nodes (i, j) at one quadrature point
+//   D_rc = (g_i . sigma . g_j) delta_rc + (B_i C B_j^T)_rc ,  g = grad phi       (hyperelastic.h:68-87)
+// is, because c is symmetric in (i,j) and in (k,l) so the Voigt lookup is exact,
+//   (B_i C B_j^T)_rc = sum_st g_i[s] g_j[t] c_(rs)(ct)
+//                    = [ alpha (Q g_i)_r g_j[c] - beta ( M_rc (n_i . g_j) + (M g_j)_r n_i[c] ) ] / det F ,
+//   n_i = M^T g_i .
+// Work split inside a workgroup of 128 threads = 128 / NEN elements:
+//   phase 1  thread (element, q): shape gradients, F, M, Q, sigma at quadrature point q -> LDS
+//            (TET4: gradients are constant, one point with the summed weight)
+//   phase 2  thread (element, i): row node i, all columns j, loop over the points read from LDS
+//   phase 3  rows staged through LDS so that the element matrices leave as contiguous 16-byte stores.
+// ================================================================================================
+template <int NEN> struct SolidCfg;
+template <> struct SolidCfg<8> { static constexpr int NQ = 8, EPB = 16, PSTRIDE = 49, ESTRIDE = 8 * 49 + 1, ROW = 74, HALVES = 2; };
+template <> struct SolidCfg<4> { static constexpr int NQ = 1, EPB = 32, PSTRIDE = 35, ESTRIDE = 35, ROW = 38, HALVES = 1; };
+template <int NEN> struct SolidLds {
+  using C = SolidCfg<NEN>;
+  static constexpr int CSTRIDE = NEN * 6 + 1;
+  static constexpr int POINTS = C::EPB * C::ESTRIDE;
+  static constexpr int STAGE = (C::EPB / C::HALVES) * NEN * C::ROW;
+  static constexpr int COORDS = C::EPB * CSTRIDE;
+  static constexpr int DOUBLES = (POINTS > STAGE ? (POINTS > COORDS ? POINTS : COORDS) : (STAGE > COORDS ? STAGE : COORDS));
+};
+
+template <int NEN, bool JAC, bool SYM>
+__global__ void __launch_bounds__(128)
+k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __restrict__ fibre,
+             const int32_t* __restrict__ elem_material, const rdc_solid_material* __restrict__ materials,
+             double pseudo_time, double* __restrict__ ke, double* __restrict__ fe) {
+  using C = SolidCfg<NEN>;
+  using L = SolidLds<NEN>;
+  constexpr int NB = NEN * 9;  // doubles of one row (node i, all j) of the element matrix
+  __shared__ __attribute__((aligned(16))) double lds[L::DOUBLES];
+  const int tid = threadIdx.x;
+  const int el = tid / NEN, li = tid % NEN;
+  const int64_t e0 = (int64_t)blockIdx.x * C::EPB;
+  const int64_t e = e0 + el;
+  const bool live = e < m.n_elem;
+  // ---- phase 0: node coordinates of the workgroup's elements ---------------------------------
+  int64_t I = 0;
+  if (live) {
+    I = m.conn[e * NEN + li];
+    double* c = lds + el * L::CSTRIDE + li * 6;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { c[d] = m.xyz[3 * I + d]; c[3 + d] = Xu[3 * I + d]; }
+  }
+  __syncthreads();
+  double X[NEN][3], XU[NEN][3];
+  if (live && li < C::NQ) {
+#pragma unroll
+    for (int n = 0; n < NEN; n++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        X[n][d] = lds[el * L::CSTRIDE + n * 6 + d];
+        XU[n][d] = lds[el * L::CSTRIDE + n * 6 + 3 + d];
+      }
+  }
+  __syncthreads();
+  // ---- phase 1: one quadrature point per thread -----------------------------------------------
+  if (live && li < C::NQ) {
+    double N[NEN], G[NEN][3], W;
+    if (NEN == 8) fe_point<NEN>(X, li, N, G, W);
+    else {  // constant gradients: one evaluation carries the summed weight of the five points
+      double w = 0.0;
+#pragma unroll
+      for (int q = 0; q < Ref<NEN>::NQP; q++) { fe_point<NEN>(X, q, N, G, W); w += W; }
+      W = w;
+    }
+    double gX[3][3];  // gradX[d][c] = sum_l dphi_l[c] * X_l[d], solid_system.C:221-229
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < NEN; l++) s += G[l][c] * XU[l][d];
+        gX[d][c] = s;
+      }
+    const rdc_solid_material mat = materials[elem_material[e]];   // src/solid_system.C:183-190
+    const double mu = 0.5 * mat.Young / (1.0 + mat.Poisson);      // hyperlastic_inline.h:21-24
+    const double lame = mat.Young * mat.Poisson / ((1.0 + mat.Poisson) * (1.0 - 2.0 * mat.Poisson));
+    const double K = mat.FibreStiffness;
+    double A[3] = {0.0, 0.0, 0.0};
+    if (K > 0.0) {                                                // hyperelastic.h:46
+      const double f0 = fibre[3 * e], f1 = fibre[3 * e + 1], f2 = fibre[3 * e + 2];
+      const double nrm = sqrt(f0 * f0 + f1 * f1 + f2 * f2);
+      A[0] = f0 / nrm; A[1] = f1 / nrm; A[2] = f2 / nrm;
+    }
+    const double Kf = (K > 0.0) ? K : 0.0;
+    double lam[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) lam[d] = 1.0 + pseudo_time * mat.rate[d];  // solid_system.C:232-234
+    // F = gradX^-1
+    const double c00 = gX[1][1] * gX[2][2] - gX[1][2] * gX[2][1];
+    const double c01 = gX[1][2] * gX[2][0] - gX[1][0] * gX[2][2];
+    const double c02 = gX[1][0] * gX[2][1] - gX[1][1] * gX[2][0];
+    const double s = 1.0 / (gX[0][0] * c00 + gX[0][1] * c01 + gX[0][2] * c02);
+    double F[3][3];
+    F[0][0] = c00 * s;
+    F[0][1] = (gX[0][2] * gX[2][1] - gX[0][1] * gX[2][2]) * s;
+    F[0][2] = (gX[0][1] * gX[1][2] - gX[0][2] * gX[1][1]) * s;
+    F[1][0] = c01 * s;
+    F[1][1] = (gX[0][0] * gX[2][2] - gX[0][2] * gX[2][0]) * s;
+    F[1][2] = (gX[0][2] * gX[1][0] - gX[0][0] * gX[1][2]) * s;
+    F[2][0] = c02 * s;
+    F[2][1] = (gX[0][1] * gX[2][0] - gX[0][0] * gX[2][1]) * s;
+    F[2][2] = (gX[0][0] * gX[1][1] - gX[0][1] * gX[1][0]) * s;
+    const double detF = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) +
+                        F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+    const double Jr = 1.0 / detF;
+    const double Je = detF / (lam[0] * lam[1] * lam[2]);
+    double M[3][3], fa[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      fa[i] = F[i][0] * A[0] + F[i][1] * A[1] + F[i][2] * A[2];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        M[i][j] = F[i][0] * lam[0] * gX[0][j] + F[i][1] * lam[1] * gX[1][j] + F[i][2] * lam[2] * gX[2][j];
+    }
+    const double dWdJe = (-mu / Je) + (lame / 2.0 * Je - lame / 2.0 / Je);          // hyperlastic_inline.h:42
+    const double d2W = (mu / Je / Je) + (lame / 2.0 + lame / 2.0 / Je / Je);        // :47
+    const double beta = Je * dWdJe;
+    const double alpha = beta + Je * Je * d2W;
+    double* pd = lds + el * C::ESTRIDE + (NEN == 8 ? li : 0) * C::PSTRIDE;
+#pragma unroll
+    for (int n = 0; n < NEN; n++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) pd[3 * n + d] = G[n][d];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) pd[3 * NEN + 3 * i + j] = M[i][j];
+    const int V[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {1, 2}, {0, 2}};  // hyperelastic.h:15-20
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+      const int i = V[p][0], j = V[p][1];
+      const double q = M[i][0] * M[j][0] + M[i][1] * M[j][1] + M[i][2] * M[j][2];
+      const double b = F[i][0] * F[j][0] + F[i][1] * F[j][1] + F[i][2] * F[j][2];
+      pd[3 * NEN + 9 + p] = q;
+      pd[3 * NEN + 15 + p] = (mu * b + beta * q - Kf * fa[i] * fa[j]) * Jr * W;  // sigma * JxW
+    }
+    pd[3 * NEN + 21] = alpha * Jr * W;
+    pd[3 * NEN + 22] = beta * Jr * W;
+  }
+  __syncthreads();
+  // ---- phase 2: row node li of element el -------------------------------------------------------
+  double acc[NEN][3][3], re[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < NEN; j++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) acc[j][r][c] = 0.0;
+  if (live && I < m.n_owned) {
+#pragma unroll 1
+    for (int q = 0; q < C::NQ; q++) {
+      const double* pd = lds + el * C::ESTRIDE + q * C::PSTRIDE;
+      const double* pm = pd + 3 * NEN;
+      const double gi[3] = {pd[3 * li], pd[3 * li + 1], pd[3 * li + 2]};
+      double M[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) M[a][b] = pm[3 * a + b];
+      const double Q[3][3] = {{pm[9], pm[12], pm[14]}, {pm[12], pm[10], pm[13]}, {pm[14], pm[13], pm[11]}};
+      const double S[3][3] = {{pm[15], pm[18], pm[20]}, {pm[18], pm[16], pm[19]}, {pm[20], pm[19], pm[17]}};
+      const double aW = pm[21], bW = pm[22];
+      double ap[3], bn[3], sg[3], mi[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        ap[r] = aW * (Q[r][0] * gi[0] + Q[r][1] * gi[1] + Q[r][2] * gi[2]);
+        bn[r] = bW * (M[0][r] * gi[0] + M[1][r] * gi[1] + M[2][r] * gi[2]);
+        sg[r] = S[r][0] * gi[0] + S[r][1] * gi[1] + S[r][2] * gi[2];
+        mi[r] = M[r][0] * gi[0] + M[r][1] * gi[1] + M[r][2] * gi[2];
+        re[r] += sg[r];   // B_i sigma_voigt * JxW, hyperelastic.h:52-66
+      }
+      if (!JAC) continue;
+#pragma unroll
+      for (int j = 0; j < NEN; j++) {
+        const double gj[3] = {pd[3 * j], pd[3 * j + 1], pd[3 * j + 2]};
+        if (SYM && j < li) {
+          // use_symmetry: block (i, j) with j < i is the transpose of block (j, i), solid_system.C:252-262
+          double apj[3], bnj[3], sgj[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            apj[r] = aW * (Q[r][0] * gj[0] + Q[r][1] * gj[1] + Q[r][2] * gj[2]);
+            bnj[r] = bW * (M[0][r] * gj[0] + M[1][r] * gj[1] + M[2][r] * gj[2]);
+            sgj[r] = S[r][0] * gj[0] + S[r][1] * gj[1] + S[r][2] * gj[2];
+          }
+          const double kap = bnj[0] * gi[0] + bnj[1] * gi[1] + bnj[2] * gi[2];
+          const double gam = sgj[0] * gi[0] + sgj[1] * gi[1] + sgj[2] * gi[2];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+              acc[j][r][c] += apj[c] * gi[r] - (M[c][r] * kap + mi[c] * bnj[r]) + (r == c ? gam : 0.0);
+          continue;
+        }
+        const double kap = bn[0] * gj[0] + bn[1] * gj[1] + bn[2] * gj[2];
+        const double gam = sg[0] * gj[0] + sg[1] * gj[1] + sg[2] * gj[2];
+        double mj[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) mj[r] = M[r][0] * gj[0] + M[r][1] * gj[1] + M[r][2] * gj[2];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            acc[j][r][c] += ap[r] * gj[c] - (M[r][c] * kap + mj[r] * bn[c]) + (r == c ? gam : 0.0);
+      }
+    }
+  }
+  if (live) {
+    double* f = fe + (e * NEN + li) * 3;
+    f[0] = re[0]; f[1] = re[1]; f[2] = re[2];
+  }
+  if (!JAC) return;
+  // ---- phase 3: rows -> LDS -> contiguous 16-byte stores -------------------------------------------
+  constexpr int EPH = C::EPB / C::HALVES;  // elements per staging pass
+#pragma unroll 1
+  for (int h = 0; h < C::HALVES; h++) {
+    __syncthreads();
+    if (el / EPH == h) {
+      double* row = lds + ((el % EPH) * NEN + li) * C::ROW;
+#pragma unroll
+      for (int j = 0; j < NEN; j++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) row[j * 9 + 3 * r + c] = acc[j][r][c];
+    }
+    __syncthreads();
+    const int64_t eb = e0 + (int64_t)h * EPH;
+    int64_t nrows = (m.n_elem - eb) * NEN;
+    if (nrows > EPH * NEN) nrows = EPH * NEN;
+    const int n2 = (int)(nrows > 0 ? nrows : 0) * (NB / 2);  // 16-byte units
+    double* dst = ke + eb * NEN * NB;
+    for (int x = tid; x < n2; x += 128) {
+      const int rw = x / (NB / 2), k2 = x - rw * (NB / 2);
+      const double2 v = *reinterpret_cast<const double2*>(lds + rw * C::ROW + 2 * k2);
+      __builtin_nontemporal_store(v.x, dst + 2 * x);
+      __builtin_nontemporal_store(v.y, dst + 2 * x + 1);
+    }
+  }
+}
+
+// pass 2: one thread per node block of the owned rows
+template <bool JAC>
+__global__ void __launch_bounds__(256)
+k_solid_gather(int64_t nblocks, const int64_t* __restrict__ bptr, const int32_t* __restrict__ brow,
+               const uint32_t* __restrict__ gptr, const uint32_t* __restrict__ gsrc, const double* __restrict__ ke,
+               double* __restrict__ val) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  double a[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (JAC) {
+    const uint32_t s1 = gptr[b + 1];
+    for (uint32_t s = gptr[b]; s < s1; s++) {
+      const double* k = ke + (int64_t)gsrc[s] * 9;
+#pragma unroll
+      for (int x = 0; x < 9; x++) a[x] += k[x];
+    }
+  }
+  // when no Jacobian is requested the matrix is still rewritten (zeros) so stale values never survive
+  const int64_t I = brow[b];
+  const int64_t b0 = bptr[I], len = bptr[I + 1] - b0;
+  double* row = val + 9 * b0 + 3 * (b - b0);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) __builtin_nontemporal_store(a[3 * r + c], row + r * 3 * len + c);
+}
+
+// rhs: one thread per owned node sums the rows of its incident (element, local node) pairs
+__global__ void __launch_bounds__(256)
+k_solid_gather_rhs(int64_t n_owned, int nen, const int64_t* __restrict__ node_pair_ptr,
+                   const uint32_t* __restrict__ pair_elem, const uint8_t* __restrict__ pair_local,
+                   const double* __restrict__ fe, double* __restrict__ rhs) {
+  const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (I >= n_owned) return;
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+  for (int64_t p = node_pair_ptr[I]; p < node_pair_ptr[I + 1]; p++) {
+    const double* f = fe + ((int64_t)pair_elem[p] * nen + pair_local[p]) * 3;
+    r0 += f[0]; r1 += f[1]; r2 += f[2];
+  }
+  rhs[3 * I] = r0; rhs[3 * I + 1] = r1; rhs[3 * I + 2] = r2;
+}
+
+template <int NEN>
+static void launch_two_pass(const SolidArgs& a) {
+  const unsigned grid = (unsigned)((a.m.n_elem + SolidCfg<NEN>::EPB - 1) / SolidCfg<NEN>::EPB);
+#define RDC_SOLID_ELEM(JAC, SYM)                                                                                   \
+  hipLaunchKernelGGL((k_solid_elem<NEN, JAC, SYM>), dim3(grid), dim3(128), 0, a.stream, a.m, a.Xu, a.fibre,      \
+                     a.elem_material, a.materials, a.params.pseudo_time, a.ke, a.fe)
+  if (!a.request_jacobian) RDC_SOLID_ELEM(false, false);
+  else if (a.params.use_symmetry) RDC_SOLID_ELEM(true, true);
+  else RDC_SOLID_ELEM(true, false);
+#undef RDC_SOLID_ELEM
+  const unsigned gb = (unsigned)((a.nblocks + 255) / 256);
+  if (a.request_jacobian)
+    hipLaunchKernelGGL((k_solid_gather<true>), dim3(gb), dim3(256), 0, a.stream, a.nblocks, a.m.bptr, a.brow, a.gptr, a.gsrc,
+                       a.ke, a.val);
+  else
+    hipLaunchKernelGGL((k_solid_gather<false>), dim3(gb), dim3(256), 0, a.stream, a.nblocks, a.m.bptr, a.brow, a.gptr,
+                       a.gsrc, a.ke, a.val);
+  const unsigned gn = (unsigned)((a.m.n_owned + 255) / 256);
+  hipLaunchKernelGGL(k_solid_gather_rhs, dim3(gn), dim3(256), 0, a.stream, a.m.n_owned, NEN, a.m.node_pair_ptr,
+                     a.m.pair_elem, a.m.pair_local, a.fe, a.rhs);
+}
+
 hipError_t launch_solid(const SolidArgs& a) {
+  if (a.kernel == 0) {
+    if (a.nen == 4) launch_two_pass<4>(a); else launch_two_pass<8>(a);
+  } else
   for (int c = 0; c < a.n_colours; c++) {
     const int64_t first = a.colour_ptr[c], count = a.colour_ptr[c + 1] - first;
     if (count <= 0) continue;

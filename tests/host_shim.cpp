@@ -100,6 +100,7 @@ int masks(const P* p, const double* u, const double* aux, double* worst) {
 }
 
 HostPrep g_prep;
+SolidGather g_gather;
 std::string g_err;
 
 }  // namespace
@@ -138,6 +139,11 @@ int shim_prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, co
   return g_err.empty() ? 0 : 1;
 }
 const char* shim_prep_error() { return g_err.c_str(); }
+// gather lists of the two-pass solid assembly, from the last shim_prep_build
+int shim_solid_gather_build() {
+  g_err = solid_gather_build(g_prep, g_gather);
+  return g_err.empty() ? 0 : 1;
+}
 int64_t shim_prep_size(int what) {
   switch (what) {
     case 0: return (int64_t)g_prep.bptr.size();
@@ -158,6 +164,9 @@ int64_t shim_prep_size(int what) {
     case 15: return (int64_t)(g_prep.chunk.size() * sizeof(HostPrep::Chunk));
     case 16: return (int64_t)(g_prep.sdesc.size() * sizeof(HostPrep::StoreDesc));
     case 17: return (int64_t)g_prep.contrib.size();
+    case 20: return (int64_t)g_gather.gptr.size();
+    case 21: return (int64_t)g_gather.gsrc.size();
+    case 22: return (int64_t)g_gather.brow.size();
     case 100: return g_prep.n_colours;
     case 101: return g_prep.rowgather_ok ? 1 : 0;
     case 102: return (int64_t)g_prep.rg_lds_bytes;
@@ -190,6 +199,13 @@ int shim_prep_copy(int what, void* dst) {
     case 17: CP(contrib);
   }
 #undef CP
+#define CG(v) std::memcpy(dst, g_gather.v.data(), g_gather.v.size() * sizeof(g_gather.v[0])); return 0
+  switch (what) {
+    case 20: CG(gptr);
+    case 21: CG(gsrc);
+    case 22: CG(brow);
+  }
+#undef CG
   return 1;
 }
 

@@ -182,12 +182,14 @@ def _solid_case(nen, n, seed=0):
 @pytest.mark.parametrize("nen,n", [(8, 5), (4, 4)])
 @pytest.mark.parametrize("use_symmetry", [0, 1])
 @pytest.mark.parametrize("jac", [True, False])
-def test_solid_parity(oracle, nen, n, use_symmetry, jac):
+@pytest.mark.parametrize("solid_kernel", [0, 1])
+def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel):
     conn, Xu, x, em, mats, fibre, sides = _solid_case(nen, n)
     sp = SolidParams(0.4, 1.0e5, use_symmetry, 0)
     _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_SOLID, nen, conn, x, 3, sp, xyz_undeformed=Xu, elem_fibre=fibre,
                                        elem_material=em, materials=mats, request_jacobian=jac, sides=sides)
     with AssemblyContext(0) as ctx:
+        ctx.set_option("solid_kernel", solid_kernel)   # 0 = two-pass (default), 1 = coloured
         ctx.mesh_upload(nen, conn, x, 3)
         ctx.field_upload(FIELD_UNDEFORMED_XYZ, Xu)
         ctx.field_upload(FIELD_ELEM_FIBRE, fibre)
@@ -195,11 +197,17 @@ def test_solid_parity(oracle, nen, n, use_symmetry, jac):
         ctx.solid_set_sides(*sides)
         ctx.solid_assemble(sp, jac)
         val, rhs = ctx.csr_download()
+        ctx.solid_assemble(sp, jac)                    # repeatable (buffers reused), and deterministic
+        val2, rhs2 = ctx.csr_download()
     assert rel(rhs, rhs0) < TOL
     if jac:
         assert rel(val, val0) < TOL
     else:
         assert np.all(val == 0.0)
+    if solid_kernel == 0 and sides[0].size == 0:
+        assert np.array_equal(val, val2) and np.array_equal(rhs, rhs2)
+    else:
+        assert rel(rhs2, rhs0) < TOL
 
 
 def test_clamp_nonnegative(oracle):

@@ -2,6 +2,7 @@
 colouring, first-writer masks and row-gather work lists.  The scatter index arithmetic of both
 kernels is replayed here in numpy on top of the product's row function and compared with the
 oracle's MatSetValues-style assembly."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -275,3 +276,31 @@ def test_prep_rejects_bad_meshes(make_prep):
     # empty owned set is legal (a rank that owns nothing): nothing to assemble
     P = make_prep(4, conn[:0], n, 0, 1)
     assert P.ok and P.bptr.tolist() == [0]
+
+
+@pytest.mark.parametrize("nen,n_owned_frac", [(8, 1.0), (4, 1.0), (8, 0.6)])
+def test_solid_gather_lists(shim, make_prep, nen, n_owned_frac):
+    """Two-pass solid assembly: every (element, i, j) block with an owned row node is listed exactly once,
+    under the CSR block of (node i, node j), in ascending (element, i) order."""
+    conn, xyz = (synth.hex_mesh(4, order="random") if nen == 8 else synth.kuhn_tet_mesh(3, order="random"))
+    n_node = xyz.shape[0]
+    n_owned = int(n_node * n_owned_frac)
+    P = make_prep(nen, conn, n_node, n_owned, 3)
+    assert P.ok and shim.shim_solid_gather_build() == 0
+    get = lambda idx, dt: (lambda a: (shim.shim_prep_copy(idx, a.ctypes.data_as(C.c_void_p)), a)[1])(
+        np.empty(shim.shim_prep_size(idx), dtype=dt))
+    gptr, gsrc, brow = get(20, np.uint32), get(21, np.uint32), get(22, np.int32)
+    nb = int(P.bptr[n_owned])
+    assert gptr.size == nb + 1 and brow.size == nb and gptr[0] == 0 and gptr[-1] == gsrc.size
+    e, r = np.divmod(gsrc.astype(np.int64), nen * nen)
+    i, j = np.divmod(r, nen)
+    blk = np.repeat(np.arange(nb), np.diff(gptr.astype(np.int64)))
+    c = conn.astype(np.int64)
+    assert np.array_equal(c[e, i], brow[blk])
+    assert np.array_equal(c[e, j], P.bcol[blk])
+    assert np.array_equal(brow, np.repeat(np.arange(n_owned), np.diff(P.bptr[:n_owned + 1])))
+    owned_rows = int((c < n_owned).sum())
+    assert gsrc.size == owned_rows * nen and np.unique(gsrc).size == gsrc.size
+    for b in range(nb):   # fixed summation order
+        seg = gsrc[gptr[b]:gptr[b + 1]]
+        assert np.all(np.diff(seg.astype(np.int64)) > 0)

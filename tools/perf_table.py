@@ -11,8 +11,10 @@ from rdcfes_amd.context import FIELD_AUX_NODAL, FIELD_ELEM_FIBRE, FIELD_OLD_SOLU
 def b_alg(nen, ne, nn, nvar, n_in, nnz, solid=False):
     return 4 * nen * ne + 8 * 3 * nn * (2 if solid else 1) + 8 * n_in * nn + (8 * 4 * ne if solid else 0) + 8 * nnz + 8 * nvar * nn
 
-def run(name, nen, conn, xyz, nv, setup, call, scatter, reps=5, n_in=None, solid=False):
+def run(name, nen, conn, xyz, nv, setup, call, scatter, reps=5, n_in=None, solid=False, opts=()):
     with AssemblyContext(0) as ctx:
+        for k, v in opts:
+            ctx.set_option(k, v)
         t0 = time.time()
         ctx.mesh_upload(nen, conn, xyz, nv)
         prep = time.time() - t0
@@ -56,15 +58,22 @@ for w in which:
         p, u = hcc_params_from_dict(synth.hcc_param_dict("full")), synth.hcc_fields(xyz)
         for sc in (2, 1):
             run("HCC HEX8 H(126)", 8, conn, xyz, 3, lambda c: c.field_upload(FIELD_OLD_SOLUTION, u), lambda c: c.assemble_hcc(p), sc, reps=3)
-    elif w == "solid63":
-        conn, Xu = synth.hex_mesh(63, jitter=0.1)
+    elif w.startswith("solid"):
+        n = int(w.replace("solid", "").replace("tet", "") or 63)
+        tet = w.endswith("tet")
+        conn, Xu = synth.kuhn_tet_mesh(n, jitter=0.1) if tet else synth.hex_mesh(n, jitter=0.1)
+        nen = 4 if tet else 8
         x = Xu + synth.solid_displacement(Xu)
         em = (np.linalg.norm(Xu[conn].mean(axis=1) - 0.5, axis=1) < 0.3).astype(np.int32)
         mats = [SolidMaterial(2.0e3, 0.4, 0.0, (0.0, 0.0, 0.0)), SolidMaterial(2.0e3, 0.4, 0.0, (0.3, 0.3, 0.3))]
-        se0, ss0 = synth.boundary_sides(8, conn, Xu, 2, 0.0)
+        se0, ss0 = synth.boundary_sides(nen, conn, Xu, 2, 0.0)
         sd = np.zeros((se0.size, 3))
         sp = SolidParams(0.4, 1.0e8, 0, 0)
         def setup(c):
             c.field_upload(FIELD_UNDEFORMED_XYZ, Xu); c.field_upload(FIELD_ELEM_FIBRE, np.tile([0.0, 0.0, 1.0], (conn.shape[0], 1)))
             c.solid_set_materials(em, mats); c.solid_set_sides(se0, ss0, sd)
-        run("SOLID HEX8 H(63) residual+Jacobian", 8, conn, x, 3, setup, lambda c: c.solid_assemble(sp, True), 1, reps=3, n_in=0, solid=True)
+        for sk in ((0, 1) if conn.shape[0] <= 300000 else (0,)):
+            run(f"SOLID {'TET4 K' if tet else 'HEX8 H'}({n}) residual+Jacobian, solid_kernel={sk}", nen, conn, x, 3, setup,
+                lambda c: c.solid_assemble(sp, True), 1, reps=3, n_in=0, solid=True, opts=(("solid_kernel", sk),))
+            run(f"SOLID {'TET4 K' if tet else 'HEX8 H'}({n}) residual only, solid_kernel={sk}", nen, conn, x, 3, setup,
+                lambda c: c.solid_assemble(sp, False), 1, reps=3, n_in=0, solid=True, opts=(("solid_kernel", sk),))
