@@ -28,6 +28,8 @@ struct SolidArgs {
   const uint32_t* gptr;
   const uint32_t* gsrc;
   const int32_t* brow;
+  int split;                   // pass 1: 1 = one thread per element row (default), 0 = columns of a HEX8 row split between two threads
+  int gather;                  // pass 2: 0 = stores staged through LDS (runs of consecutive doubles), 1 = 24-byte pieces
 };
 hipError_t launch_solid(const SolidArgs& a);
 }  // namespace rdc

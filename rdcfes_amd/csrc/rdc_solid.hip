@@ -340,8 +340,12 @@ template <int NEN> struct SolidLds {
   static constexpr int DOUBLES = (POINTS > STAGE ? (POINTS > COORDS ? POINTS : COORDS) : (STAGE > COORDS ? STAGE : COORDS));
 };
 
-template <int NEN, bool JAC, bool SYM>
-__global__ void __launch_bounds__(128)
+typedef double rdc_v2d __attribute__((ext_vector_type(2)));
+
+// JS = 2 splits the columns of a row between two threads (HEX8: 256 threads, 36 accumulators each): twice
+// the waves per LDS byte to hide the LDS / global latencies of the phases.
+template <int NEN, bool JAC, bool SYM, int JS>
+__global__ void __launch_bounds__(128 * JS)
 k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __restrict__ fibre,
              const int32_t* __restrict__ elem_material, const rdc_solid_material* __restrict__ materials,
              double pseudo_time, double* __restrict__ ke, double* __restrict__ fe) {
@@ -349,22 +353,24 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
   using L = SolidLds<NEN>;
   constexpr int NB = NEN * 9;  // doubles of one row (node i, all j) of the element matrix
   __shared__ __attribute__((aligned(16))) double lds[L::DOUBLES];
+  constexpr int NT = 128 * JS, NJ = NEN / JS;
   const int tid = threadIdx.x;
-  const int el = tid / NEN, li = tid % NEN;
+  const int jh = tid / 128;                       // column half; waves of half 1 skip phases 0 and 1
+  const int el = (tid % 128) / NEN, li = tid % NEN;
   const int64_t e0 = (int64_t)blockIdx.x * C::EPB;
   const int64_t e = e0 + el;
   const bool live = e < m.n_elem;
   // ---- phase 0: node coordinates of the workgroup's elements ---------------------------------
   int64_t I = 0;
-  if (live) {
-    I = m.conn[e * NEN + li];
+  if (live) I = m.conn[e * NEN + li];
+  if (live && jh == 0) {
     double* c = lds + el * L::CSTRIDE + li * 6;
 #pragma unroll
     for (int d = 0; d < 3; d++) { c[d] = m.xyz[3 * I + d]; c[3 + d] = Xu[3 * I + d]; }
   }
   __syncthreads();
   double X[NEN][3], XU[NEN][3];
-  if (live && li < C::NQ) {
+  if (live && jh == 0 && li < C::NQ) {
 #pragma unroll
     for (int n = 0; n < NEN; n++)
 #pragma unroll
@@ -375,7 +381,7 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
   }
   __syncthreads();
   // ---- phase 1: one quadrature point per thread -----------------------------------------------
-  if (live && li < C::NQ) {
+  if (live && jh == 0 && li < C::NQ) {
     double N[NEN], G[NEN][3], W;
     if (NEN == 8) fe_point<NEN>(X, li, N, G, W);
     else {  // constant gradients: one evaluation carries the summed weight of the five points
@@ -462,9 +468,9 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
   }
   __syncthreads();
   // ---- phase 2: row node li of element el -------------------------------------------------------
-  double acc[NEN][3][3], re[3] = {0.0, 0.0, 0.0};
+  double acc[NJ][3][3], re[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-  for (int j = 0; j < NEN; j++)
+  for (int j = 0; j < NJ; j++)
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -494,7 +500,8 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
       }
       if (!JAC) continue;
 #pragma unroll
-      for (int j = 0; j < NEN; j++) {
+      for (int jj = 0; jj < NJ; jj++) {
+        const int j = jh * NJ + jj;
         const double gj[3] = {pd[3 * j], pd[3 * j + 1], pd[3 * j + 2]};
         if (SYM && j < li) {
           // use_symmetry: block (i, j) with j < i is the transpose of block (j, i), solid_system.C:252-262
@@ -510,8 +517,12 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
 #pragma unroll
           for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-              acc[j][r][c] += apj[c] * gi[r] - (M[c][r] * kap + mi[c] * bnj[r]) + (r == c ? gam : 0.0);
+            for (int c = 0; c < 3; c++) {
+              double v = fma(apj[c], gi[r], acc[jj][r][c]);
+              v = fma(-M[c][r], kap, v);
+              v = fma(-mi[c], bnj[r], v);
+              acc[jj][r][c] = (r == c) ? v + gam : v;
+            }
           continue;
         }
         const double kap = bn[0] * gj[0] + bn[1] * gj[1] + bn[2] * gj[2];
@@ -522,12 +533,16 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int c = 0; c < 3; c++)
-            acc[j][r][c] += ap[r] * gj[c] - (M[r][c] * kap + mj[r] * bn[c]) + (r == c ? gam : 0.0);
+          for (int c = 0; c < 3; c++) {
+            double v = fma(ap[r], gj[c], acc[jj][r][c]);
+            v = fma(-M[r][c], kap, v);
+            v = fma(-mj[r], bn[c], v);
+            acc[jj][r][c] = (r == c) ? v + gam : v;
+          }
       }
     }
   }
-  if (live) {
+  if (live && jh == 0) {
     double* f = fe + (e * NEN + li) * 3;
     f[0] = re[0]; f[1] = re[1]; f[2] = re[2];
   }
@@ -538,9 +553,9 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
   for (int h = 0; h < C::HALVES; h++) {
     __syncthreads();
     if (el / EPH == h) {
-      double* row = lds + ((el % EPH) * NEN + li) * C::ROW;
+      double* row = lds + ((el % EPH) * NEN + li) * C::ROW + jh * NJ * 9;
 #pragma unroll
-      for (int j = 0; j < NEN; j++)
+      for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -552,11 +567,10 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
     if (nrows > EPH * NEN) nrows = EPH * NEN;
     const int n2 = (int)(nrows > 0 ? nrows : 0) * (NB / 2);  // 16-byte units
     double* dst = ke + eb * NEN * NB;
-    for (int x = tid; x < n2; x += 128) {
+    for (int x = tid; x < n2; x += NT) {
       const int rw = x / (NB / 2), k2 = x - rw * (NB / 2);
-      const double2 v = *reinterpret_cast<const double2*>(lds + rw * C::ROW + 2 * k2);
-      __builtin_nontemporal_store(v.x, dst + 2 * x);
-      __builtin_nontemporal_store(v.y, dst + 2 * x + 1);
+      const rdc_v2d v = *reinterpret_cast<const rdc_v2d*>(lds + rw * C::ROW + 2 * k2);
+      __builtin_nontemporal_store(v, reinterpret_cast<rdc_v2d*>(dst) + x);
     }
   }
 }
@@ -603,23 +617,67 @@ k_solid_gather_rhs(int64_t n_owned, int nen, const int64_t* __restrict__ node_pa
   rhs[3 * I] = r0; rhs[3 * I + 1] = r1; rhs[3 * I + 2] = r2;
 }
 
+// pass 2, staged form (default): 256 consecutive node blocks per workgroup, one thread each as above, but
+// the nine sums go through LDS so that the three row pieces of the blocks leave as runs of consecutive
+// doubles (a node's blocks are consecutive in each of its three CSR rows) instead of 24-byte pieces.
+__global__ void __launch_bounds__(256)
+k_solid_gather_st(int64_t nblocks, const int64_t* __restrict__ bptr, const int32_t* __restrict__ brow,
+                  const uint32_t* __restrict__ gptr, const uint32_t* __restrict__ gsrc, const double* __restrict__ ke,
+                  double* __restrict__ val) {
+  __shared__ double img[3][3 * 256];
+  __shared__ int64_t obase[256];   // value index of (row 0, column 0) of the block
+  __shared__ int32_t ostride[256]; // 3 * blocks in the row of its node
+  const int64_t B0 = (int64_t)blockIdx.x * 256;
+  const int64_t b = B0 + threadIdx.x;
+  if (b < nblocks) {
+    double a[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const uint32_t s1 = gptr[b + 1];
+    for (uint32_t s = gptr[b]; s < s1; s++) {
+      const double* k = ke + (int64_t)gsrc[s] * 9;
+#pragma unroll
+      for (int x = 0; x < 9; x++) a[x] += k[x];
+    }
+    const int64_t I = brow[b];
+    const int64_t nb0 = bptr[I], len = bptr[I + 1] - nb0;
+    obase[threadIdx.x] = 9 * nb0 + 3 * (b - nb0);
+    ostride[threadIdx.x] = (int32_t)(3 * len);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) img[r][3 * threadIdx.x + c] = a[3 * r + c];
+  }
+  __syncthreads();
+  const int64_t rem = nblocks - B0;
+  const int nx = 3 * (int)(rem < 256 ? rem : 256);
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    for (int x = threadIdx.x; x < nx; x += 256) {
+      const int tb = x / 3, c = x - 3 * tb;
+      __builtin_nontemporal_store(img[r][x], val + obase[tb] + (int64_t)r * ostride[tb] + c);
+    }
+}
+
 template <int NEN>
 static void launch_two_pass(const SolidArgs& a) {
   const unsigned grid = (unsigned)((a.m.n_elem + SolidCfg<NEN>::EPB - 1) / SolidCfg<NEN>::EPB);
-#define RDC_SOLID_ELEM(JAC, SYM)                                                                                   \
-  hipLaunchKernelGGL((k_solid_elem<NEN, JAC, SYM>), dim3(grid), dim3(128), 0, a.stream, a.m, a.Xu, a.fibre,      \
+#define RDC_SOLID_ELEM(JAC, SYM, JS)                                                                                \
+  hipLaunchKernelGGL((k_solid_elem<NEN, JAC, SYM, JS>), dim3(grid), dim3(128 * JS), 0, a.stream, a.m, a.Xu, a.fibre, \
                      a.elem_material, a.materials, a.params.pseudo_time, a.ke, a.fe)
-  if (!a.request_jacobian) RDC_SOLID_ELEM(false, false);
-  else if (a.params.use_symmetry) RDC_SOLID_ELEM(true, true);
-  else RDC_SOLID_ELEM(true, false);
+  constexpr int JSD = (NEN == 8) ? 2 : 1;
+  if (!a.request_jacobian) RDC_SOLID_ELEM(false, false, 1);
+  else if (a.params.use_symmetry) RDC_SOLID_ELEM(true, true, JSD);
+  else if (a.split == 1) RDC_SOLID_ELEM(true, false, 1);
+  else RDC_SOLID_ELEM(true, false, JSD);
 #undef RDC_SOLID_ELEM
   const unsigned gb = (unsigned)((a.nblocks + 255) / 256);
-  if (a.request_jacobian)
+  if (a.request_jacobian && a.gather == 0)
+    hipLaunchKernelGGL(k_solid_gather_st, dim3(gb), dim3(256), 0, a.stream, a.nblocks, a.m.bptr, a.brow, a.gptr, a.gsrc, a.ke,
+                       a.val);
+  else if (a.request_jacobian)
     hipLaunchKernelGGL((k_solid_gather<true>), dim3(gb), dim3(256), 0, a.stream, a.nblocks, a.m.bptr, a.brow, a.gptr, a.gsrc,
                        a.ke, a.val);
-  else
-    hipLaunchKernelGGL((k_solid_gather<false>), dim3(gb), dim3(256), 0, a.stream, a.nblocks, a.m.bptr, a.brow, a.gptr,
-                       a.gsrc, a.ke, a.val);
+  else  // the matrix is still rewritten (zeros) so that stale values never survive
+    (void)hipMemsetAsync(a.val, 0, (size_t)a.nblocks * 9 * sizeof(double), a.stream);
   const unsigned gn = (unsigned)((a.m.n_owned + 255) / 256);
   hipLaunchKernelGGL(k_solid_gather_rhs, dim3(gn), dim3(256), 0, a.stream, a.m.n_owned, NEN, a.m.node_pair_ptr,
                      a.m.pair_elem, a.m.pair_local, a.fe, a.rhs);

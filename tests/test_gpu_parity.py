@@ -182,14 +182,16 @@ def _solid_case(nen, n, seed=0):
 @pytest.mark.parametrize("nen,n", [(8, 5), (4, 4)])
 @pytest.mark.parametrize("use_symmetry", [0, 1])
 @pytest.mark.parametrize("jac", [True, False])
-@pytest.mark.parametrize("solid_kernel", [0, 1])
-def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel):
+@pytest.mark.parametrize("solid_kernel,solid_gather,solid_split", [(0, 0, 0), (0, 1, 1), (1, 0, 0)])
+def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel, solid_gather, solid_split):
     conn, Xu, x, em, mats, fibre, sides = _solid_case(nen, n)
     sp = SolidParams(0.4, 1.0e5, use_symmetry, 0)
     _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_SOLID, nen, conn, x, 3, sp, xyz_undeformed=Xu, elem_fibre=fibre,
                                        elem_material=em, materials=mats, request_jacobian=jac, sides=sides)
     with AssemblyContext(0) as ctx:
         ctx.set_option("solid_kernel", solid_kernel)   # 0 = two-pass (default), 1 = coloured
+        ctx.set_option("solid_gather", solid_gather)   # pass 2: 0 = stores staged through LDS (default), 1 = direct
+        ctx.set_option("solid_split", solid_split)     # pass 1: 0 = HEX8 row split over two threads (default), 1 = not
         ctx.mesh_upload(nen, conn, x, 3)
         ctx.field_upload(FIELD_UNDEFORMED_XYZ, Xu)
         ctx.field_upload(FIELD_ELEM_FIBRE, fibre)
