@@ -199,7 +199,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   LaunchArgs a;
   a.m = mesh_view(c);
   a.nen = c->prep.nen;
-  a.exp_mode = exp_mode_of(M::exponent(k)) == 3 ? 3 : 0;
+  a.exp_mode = exp_mode_of(M::exponent(k)) == M::FAST_EXP_MODE ? M::FAST_EXP_MODE : 0;
   rc = resolve_strategy(c, &a.strategy);
   if (rc) return rc;
   a.u = (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p;

@@ -79,6 +79,7 @@ RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
   else if (EXP_MODE == 2) { pm1 = x; p = x * x; }
   else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
   else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
+  else if (EXP_MODE == 25) { pm1 = x * sqrt(x); p = pm1 * x; }  // e = 2.5 (run/RIPF133/input.dat): one sqrt, no pow
   else { p = pow(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
 }
 
@@ -96,6 +97,7 @@ struct PihnaK {  // src/pihna.C:358-381
 
 struct Pihna {
   static constexpr int NV = 5, NG = 4, NAUX = 0;
+  static constexpr int FAST_EXP_MODE = 3;  // exponent with a dedicated kernel instantiation (shipped value)
   using K = PihnaK;
   using C = Coef<NV, NG>;
   // which nodal array feeds gradient field k: index into u (>=0)
@@ -267,11 +269,13 @@ struct RipfK {
   double phi_cc_B, phi_cc_D, phi_cc, phi_fb_B, phi_fb_D, phi_fb, phi_tol;
   double kappa, kappa_RT_c, delta, delta_RT_a, delta_RT_b;
   double lambda, lambda_RT_r, lambda_HU_r, omicro, omicro_RT_r, omicro_fb_b;
+  double i_lambda_RT_r, i_lambda_HU_r, i_omicro_RT_r;  // reciprocals: the per-point divisions become multiplies
   double omega, diffusion, haptotaxis, radiotaxis;
 };
 
 struct Ripf {
   static constexpr int NV = 3, NG = 3, NAUX = 3;
+  static constexpr int FAST_EXP_MODE = 25;  // volume_fraction/exponent = 2.5 in run/RIPF133/input.dat
   using K = RipfK;
   using C = Coef<NV, NG>;
   // gradient field sources: >=0 index into u, <0 -> aux index (-1-k)
@@ -299,6 +303,7 @@ struct Ripf {
     k.omicro_RT_r = p.omicro_RT_r ? p.omicro_RT_r : (double)p.RT_dose_total_max;
     k.omicro_fb_b = p.omicro_fb_b;
     k.omega = p.omega; k.diffusion = p.diffusion; k.haptotaxis = p.haptotaxis; k.radiotaxis = p.radiotaxis;
+    k.i_lambda_RT_r = 1.0 / k.lambda_RT_r; k.i_lambda_HU_r = 1.0 / k.lambda_HU_r; k.i_omicro_RT_r = 1.0 / k.omicro_RT_r;
     return k;
   }
   static inline double exponent(const K& k) { return k.VF_exp; }
@@ -317,9 +322,9 @@ struct Ripf {
     const double RT = aux[2];
     s.kappa_RT = k.kappa * exp(-k.kappa_RT_c * RT);                                   // :486
     s.delta_RT = k.delta * (1.0 - exp(-k.delta_RT_a * RT - k.delta_RT_b * (RT * RT)));  // :487
-    s.lambda_RT = k.lambda * (RT / k.lambda_RT_r);                                     // :488
+    s.lambda_RT = k.lambda * (RT * k.i_lambda_RT_r);                                     // :488
     {
-      const double r = RT / k.omicro_RT_r;                                            // :489
+      const double r = RT * k.i_omicro_RT_r;                                           // :489
       const double x = 4.0 * (r - r * r);
       s.omicro_RT = k.omicro * (x < 0.0 ? 0.0 : x);
     }
@@ -341,9 +346,9 @@ struct Ripf {
     if (s.fb >= 0.0 && s.fb < 1.0) {
       const double f2 = 1.0 - s.fb * s.fb;
       if (s.HU > k.lambda_HU_r && s.HU < 0.0) {
-        s.Lom = f2 * (s.HU / k.lambda_HU_r);
-        s.Lom_dHU = f2 / k.lambda_HU_r;
-        s.Lom_dfb = -(2.0 * s.fb) * (s.HU / k.lambda_HU_r);
+        s.Lom = f2 * (s.HU * k.i_lambda_HU_r);
+        s.Lom_dHU = f2 * k.i_lambda_HU_r;
+        s.Lom_dfb = -(2.0 * s.fb) * (s.HU * k.i_lambda_HU_r);
       } else if (s.HU < k.lambda_HU_r) {
         s.Lom = f2;
         s.Lom_dfb = -(2.0 * s.fb);
@@ -402,6 +407,7 @@ struct HccK {
 
 struct Hcc {
   static constexpr int NV = 3, NG = 1, NAUX = 0;
+  static constexpr int FAST_EXP_MODE = 3;
   using K = HccK;
   using C = Coef<NV, NG>;
   RDC_HD static constexpr int grad_src(int) { return 1; }
@@ -470,6 +476,7 @@ static inline int exp_mode_of(double e) {
   if (e == 2.0) return 2;
   if (e == 3.0) return 3;
   if (e == 4.0) return 4;
+  if (e == 2.5) return 25;
   return 0;
 }
 

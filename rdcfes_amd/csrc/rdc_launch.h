@@ -32,10 +32,10 @@ template <class M>
 hipError_t launch_rd(const LaunchArgs& a, const typename M::K& k) {
   if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC) return launch_tet4_fast<M>(a, k);
   if (a.nen == 4) {
-    if (a.exp_mode == 3) return launch_rd_impl<M, 4, 3>(a, k);
+    if (a.exp_mode == M::FAST_EXP_MODE) return launch_rd_impl<M, 4, M::FAST_EXP_MODE>(a, k);
     return launch_rd_impl<M, 4, 0>(a, k);
   }
-  if (a.exp_mode == 3) return launch_rd_impl<M, 8, 3>(a, k);
+  if (a.exp_mode == M::FAST_EXP_MODE) return launch_rd_impl<M, 8, M::FAST_EXP_MODE>(a, k);
   return launch_rd_impl<M, 8, 0>(a, k);
 }
 

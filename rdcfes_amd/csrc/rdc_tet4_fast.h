@@ -68,7 +68,7 @@ RDC_HD void tet4_prepare(const typename M::K& k, const double (&X)[4][3], const 
     }
     if (src < 0) {  // unit radiotherapy gradient, src/ripf.C:481-484
       const double l2 = sqrt(gf[0] * gf[0] + gf[1] * gf[1] + gf[2] * gf[2]);
-      if (l2 != 0.0) { gf[0] /= l2; gf[1] /= l2; gf[2] /= l2; }
+      if (l2 != 0.0) { const double il = rcp(l2); gf[0] *= il; gf[1] *= il; gf[2] *= il; }
       else { gf[0] = 0.0; gf[1] = 0.0; gf[2] = 0.0; }
     }
     P.gk[g] = gf[0] * G[0][0] + gf[1] * G[0][1] + gf[2] * G[0][2];

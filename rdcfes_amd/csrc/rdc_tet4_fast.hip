@@ -770,7 +770,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 
 template <class M>
 hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k) {
-  if (a.exp_mode == 3) return launch_fast_impl<M, 3>(a, k);
+  if (a.exp_mode == M::FAST_EXP_MODE) return launch_fast_impl<M, M::FAST_EXP_MODE>(a, k);
   return launch_fast_impl<M, 0>(a, k);
 }
 

@@ -63,16 +63,18 @@ template <class M, class P>
 int run(const P* p, int nen, int fast, int force_general_pow, const double* X, const double* U, const double* A,
         int irow, double* acc, double* fe) {
   const typename M::K k = M::derive(*p);
-  const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == 3;
+  // the dedicated-exponent instantiation the product would pick (Pihna/Hcc: 3, Ripf: 2.5 via sqrt)
+  constexpr int FE = M::FAST_EXP_MODE;
+  const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == FE;
   if (fast) {
     if (nen != 4) return 1;
-    if (cube) row_fast<M, 3>(k, X, U, A, irow, acc, fe); else row_fast<M, 0>(k, X, U, A, irow, acc, fe);
+    if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe); else row_fast<M, 0>(k, X, U, A, irow, acc, fe);
     return 0;
   }
   if (nen == 4) {
-    if (cube) row_generic<M, 4, 3>(k, X, U, A, irow, acc, fe); else row_generic<M, 4, 0>(k, X, U, A, irow, acc, fe);
+    if (cube) row_generic<M, 4, FE>(k, X, U, A, irow, acc, fe); else row_generic<M, 4, 0>(k, X, U, A, irow, acc, fe);
   } else if (nen == 8) {
-    if (cube) row_generic<M, 8, 3>(k, X, U, A, irow, acc, fe); else row_generic<M, 8, 0>(k, X, U, A, irow, acc, fe);
+    if (cube) row_generic<M, 8, FE>(k, X, U, A, irow, acc, fe); else row_generic<M, 8, 0>(k, X, U, A, irow, acc, fe);
   } else return 1;
   return 0;
 }

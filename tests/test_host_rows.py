@@ -67,6 +67,18 @@ def test_integer_exponent_shortcut_equals_pow(shim):
     np.testing.assert_allclose(a[1], b[1], rtol=1e-13)
 
 
+def test_half_integer_exponent_shortcut_equals_pow(shim):
+    """EXP_MODE 25 (x^2.5 = x*x*sqrt(x), the shipped RIPF exponent) against the general pow() instantiation."""
+    for nen in (4, 8):
+        X, u, aux, p = _case(1, nen, 9, "shipped")
+        assert p.VolFr_exponent == 2.5
+        for fast in ((True, False) if nen == 4 else (False,)):
+            a = shim_rows(shim, 1, nen, p, X, u, aux, fast=fast)
+            b = shim_rows(shim, 1, nen, p, X, u, aux, fast=fast, force_general_pow=True)
+            np.testing.assert_allclose(a[0], b[0], rtol=1e-12, atol=1e-14 * np.abs(b[0]).max())
+            np.testing.assert_allclose(a[1], b[1], rtol=1e-12)
+
+
 @pytest.mark.parametrize("model,variant", CASES)
 def test_structural_masks_cover_all_nonzeros(shim, model, variant):
     rng = np.random.default_rng(11)
