@@ -72,7 +72,10 @@ extern "C" {
 #define RDC_FIELD_AUX_NODAL      1  /* [n_nodes][naux]   RIPF: {cc_dtime, fb_dtime, RT_total}          */
 #define RDC_FIELD_UNDEFORMED_XYZ 2  /* [n_nodes][3]      solid: "SolidSystem::auxiliary"               */
 #define RDC_FIELD_ELEM_FIBRE     3  /* [n_elem][3]       solid: fibre direction, vars 0..2 of "::fibre" */
-#define RDC_FIELD_COUNT          4
+#define RDC_FIELD_PREV_SOLUTION  4  /* [n_nodes][nvar]   RIPF check_solution: prev_soln (src/ripf.C:675,769)         */
+#define RDC_FIELD_TIME_DERIV     5  /* [n_nodes][nvar]   "RIPF-TimeDeriv" system (src/ripf.C:738-740)                */
+#define RDC_FIELD_RT_DOSE        6  /* [n_nodes][3]      "RT" system {broad, focus, total} (src/ripf.C:749-760)      */
+#define RDC_FIELD_COUNT          7
 
 typedef struct rdc_ctx rdc_ctx;
 
@@ -197,6 +200,34 @@ int rdc_csr_download(rdc_ctx* ctx, double* val, double* rhs);
 /* ---- post-solve nodal kernel: negativity clamp of check_solution,
  * src/pihna.C:785-790, applied in place to a device-resident field ---- */
 int rdc_clamp_nonnegative(rdc_ctx* ctx, int field);
+
+/* RIPF check_solution, src/ripf.C:675-775, on device-resident fields of a 3-variable context.  Per node:
+ *   RDC_FIELD_OLD_SOLUTION  (the freshly solved state) is clamped in place: HU to [HU_min, HU_max], cc, fb >= 0 (:722-724);
+ *   RDC_FIELD_TIME_DERIV    = (clamped - RDC_FIELD_PREV_SOLUTION) / time_step                          (:738-740);
+ *   RDC_FIELD_RT_DOSE[2]    = total dose of the fractionation schedule on `day` from [0] broad, [1] focus (:754-758);
+ *   RDC_FIELD_PREV_SOLUTION = the UNCLAMPED solved state, as upstream's `prev_soln = soln`             (:769);
+ *   RDC_FIELD_AUX_NODAL     = {TIME_DERIV[1], TIME_DERIV[2], RT total}: what the next rdc_assemble_ripf reads (:470-478).
+ * *rt_total_max receives max(-1, max over the context's nodes of RT total) (:705,761); upstream stores it truncated
+ * to int in "RT_dose/total/max" and aborts when it is <= 0 (:771-772) -- with several ranks reduce it with MAX first.
+ * TIME_DERIV, AUX_NODAL are (re)allocated as needed; OLD_SOLUTION, PREV_SOLUTION, RT_DOSE must have been set. */
+typedef struct rdc_ripf_check_params {
+  double time_step;              /* "time_step"                 */
+  double HU_min, HU_max;         /* "HU/min", "HU/max"          */
+  int32_t RT_broad_fractions;    /* "RT_dose/broad/fractions"   */
+  int32_t RT_focus_fractions;    /* "RT_dose/focus/fractions"   */
+  int32_t day;                   /* floor(system.time), :703    */
+  int32_t _pad;
+} rdc_ripf_check_params;
+int rdc_ripf_check_solution(rdc_ctx* ctx, const rdc_ripf_check_params* p, double* rt_total_max);
+
+/* SolidSystem::post_process, src/solid_system.C:394-538: per element the plain average over
+ * the quadrature points of the Cauchy stress and of F*eta, then hydrostatic pressure (:522), von Mises stress (:524)
+ * -- upstream takes both from the principal stresses of eigen_decomposition (src/eig3.C:261-271); they are the
+ * invariants tr/3 and sqrt(I1^2 - 3 I2), which is what the kernel evaluates -- and the current fibre vector (:526).
+ * Uses the mesh coordinates, RDC_FIELD_UNDEFORMED_XYZ, RDC_FIELD_ELEM_FIBRE and the materials of the context.
+ * Host outputs (any may be NULL): pressure [n_elem], von_mises [n_elem], fibre_current [n_elem][3]. */
+int rdc_solid_post_process(rdc_ctx* ctx, const rdc_solid_params* p, double* pressure, double* von_mises,
+                           double* fibre_current);
 
 /* ---- instrumentation ---- */
 /* when enabled every rdc_assemble_* brackets its dominant kernel(s) -- the assembly kernel, or all

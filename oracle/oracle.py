@@ -155,6 +155,32 @@ def assemble(model, elem_type, conn, xyz, nvar, params, u_old=None, aux=None, n_
     return row_ptr, col, val, rhs
 
 
+def solid_post_process(elem_type, conn, xyz, xyz_undeformed, elem_fibre, elem_material, materials, pseudo_time):
+    """SolidSystem::post_process -> (pressure [ne], von_mises [ne], fibre_current [ne][3])"""
+    conn = np.ascontiguousarray(conn, dtype=np.uint32)
+    ne = conn.shape[0]
+    cu = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    xyz, xu, fib = cu(xyz), cu(xyz_undeformed), cu(elem_fibre)
+    em = np.ascontiguousarray(elem_material, dtype=np.int32)
+    mats = (SolidMaterial * len(materials))(*materials)
+    pr, vm, fc = np.empty(ne), np.empty(ne), np.empty((ne, 3))
+    rc = lib().oracle_solid_post_process(int(elem_type), C.c_int64(ne), _p(conn, C.c_uint32), _p(xyz), _p(xu), _p(fib),
+                                         _p(em, C.c_int32), mats, C.c_double(pseudo_time), _p(pr), _p(vm), _p(fc))
+    assert rc == 0
+    return pr, vm, fc
+
+
+def ripf_check_solution(params, sol, prev, rt):
+    """-> (clamped solution, new prev, time derivative, rt with total, aux, RT_total_max)"""
+    cp = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()
+    sol, prev, rt = cp(sol), cp(prev), cp(rt)
+    td, aux = np.empty_like(sol), np.empty_like(sol)
+    L = lib()
+    L.oracle_ripf_check_solution.restype = C.c_double
+    mx = L.oracle_ripf_check_solution(C.c_int64(sol.shape[0]), C.byref(params), _p(sol), _p(prev), _p(td), _p(rt), _p(aux))
+    return sol, prev, td, rt, aux, mx
+
+
 def clamp_nonnegative(u):
     u = np.ascontiguousarray(u, dtype=np.float64).copy()
     lib().oracle_clamp_nonnegative(_p(u), C.c_int64(u.size))

@@ -647,6 +647,81 @@ void oracle_solid_element(int nen, int nqp, const double* dphi, const double* Jx
   }
 }
 
+/* Eigenvalues of a symmetric 3x3 matrix by cyclic Jacobi rotations.  Upstream calls eigen_decomposition()
+ * (src/eig3.C:261-271, Householder tridiagonalisation + QL); only the eigenVALUES are consumed
+ * (src/solid_system.C:519-524), and both algorithms deliver them to a few ulp of |A|. */
+static void sym3_eigenvalues(const double Ain[3][3], double ev[3]) {
+  double a[3][3];
+  memcpy(a, Ain, sizeof(a));
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    if (off == 0.0) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        const int r = 3 - p - q;
+        const double app = a[p][p], aqq = a[q][q], apq = a[p][q], arp = a[r][p], arq = a[r][q];
+        a[p][p] = app - t * apq;
+        a[q][q] = aqq + t * apq;
+        a[p][q] = a[q][p] = 0.0;
+        a[r][p] = a[p][r] = c * arp - sn * arq;
+        a[r][q] = a[q][r] = sn * arp + c * arq;
+      }
+  }
+  ev[0] = a[0][0]; ev[1] = a[1][1]; ev[2] = a[2][2];
+}
+
+/* SolidSystem::post_process                                       src/solid_system.C:394-538
+ * per element: plain average over the quadrature points of the Cauchy stress and of F*eta (:500-516,526),
+ * hydrostatic pressure and von Mises stress from the principal stresses (:518-524).
+ * pressure, von_mises: [n_elem]; fibre_current: [n_elem][3]. */
+int oracle_solid_post_process(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
+                              const double* xyz_undeformed, const double* elem_fibre, const int32_t* elem_material,
+                              const rdc_solid_material* materials, double pseudo_time, double* pressure,
+                              double* von_mises, double* fibre_current) {
+  const int nen = elem_type, nqp = oracle_nqp(elem_type);
+  if (nqp < 0) return 1;
+  double X[8 * 3], XU[8 * 3], phi[8 * 8], dphi[8 * 8 * 3], JxW[8];
+  hyper_state S;
+  for (int64_t e = 0; e < n_elem; e++) {
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++)
+      for (int d = 0; d < 3; d++) {
+        X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+        XU[3 * i + d] = xyz_undeformed[3 * (int64_t)c[i] + d];
+      }
+    oracle_fe_reinit(elem_type, X, phi, dphi, JxW);
+    const rdc_solid_material* M = &materials[elem_material[e]];
+    const double* eta = elem_fibre + 3 * e;
+    double sc[3][3] = {{0}}, fv[3] = {0, 0, 0};
+    for (int q = 0; q < nqp; q++) {
+      double gradX[3][3] = {{0}}; /* :490-498 */
+      for (int d = 0; d < 3; d++)
+        for (int l = 0; l < nen; l++)
+          for (int k = 0; k < 3; k++) gradX[d][k] += DPHI(l, k) * XU[3 * l + d];
+      double lam[3];
+      for (int d = 0; d < 3; d++) lam[d] = 1.0 + pseudo_time * M->rate[d]; /* :501-503 */
+      hyper_initialize(&S, gradX, lam, eta, M->Young, M->Poisson, M->FibreStiffness, 0);
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) sc[i][j] += S.sigma[i][j];                                  /* :509 */
+        fv[i] += S.F[i][0] * eta[0] + S.F[i][1] * eta[1] + S.F[i][2] * eta[2];                   /* :511 */
+      }
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) sc[i][j] /= nqp;                                               /* :515 */
+    const double Sc[3][3] = {{sc[0][0], sc[0][1], sc[0][2]}, {sc[0][1], sc[1][1], sc[1][2]}, {sc[0][2], sc[1][2], sc[2][2]}};
+    double ev[3];
+    sym3_eigenvalues(Sc, ev);
+    pressure[e] = (ev[0] + ev[1] + ev[2]) / 3.0;                                                 /* :522 */
+    von_mises[e] = sqrt(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2] - ev[0] * ev[1] - ev[0] * ev[2] - ev[1] * ev[2]); /* :524 */
+    for (int d = 0; d < 3; d++) fibre_current[3 * e + d] = fv[d] / nqp;                          /* :526 */
+  }
+  return 0;
+}
+
 /* side tables (libMesh Tet4::side_nodes_map / Hex8::side_nodes_map) */
 static const int TET_SIDE[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {2, 0, 3}};
 static const int HEX_SIDE[6][4] = {{0, 3, 2, 1}, {0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}, {4, 5, 6, 7}};
@@ -873,6 +948,39 @@ int oracle_assemble_solid_sides(int elem_type, int64_t n_sides, const int64_t* s
   }
   free(Ke); free(Fe);
   return 0;
+}
+
+/* RIPF check_solution                                             src/ripf.C:675-775
+ * sol/prev/td/rt: [n][3]; aux: [n][3] = {cc rate, fb rate, RT total} as assemble_ripf reads them (:470-478).
+ * Returns RT_total_max (:705,761). */
+double oracle_ripf_check_solution(int64_t n, const rdc_ripf_check_params* p, double* sol, double* prev, double* td,
+                                  double* rt, double* aux) {
+  const double DT_R = 1.0 / p->time_step;                               /* :695 */
+  const double RT_broad_frac = p->RT_broad_fractions, RT_focus_frac = p->RT_focus_fractions,
+               RT_total_frac = RT_broad_frac + RT_focus_frac;           /* :699-701 */
+  const int day = p->day;                                               /* :703 */
+  double RT_total_max = -1.0;                                           /* :705 */
+  for (int64_t i = 0; i < n; i++) {
+    const double soln[3] = {sol[3 * i], sol[3 * i + 1], sol[3 * i + 2]};
+    double HU_ = soln[0], cc_ = soln[1], fb_ = soln[2];
+    if (HU_ < p->HU_min) HU_ = p->HU_min; else if (HU_ > p->HU_max) HU_ = p->HU_max; /* :722 */
+    if (cc_ < 0.0) cc_ = 0.0;
+    if (fb_ < 0.0) fb_ = 0.0;
+    sol[3 * i] = HU_; sol[3 * i + 1] = cc_; sol[3 * i + 2] = fb_;       /* :731-733 */
+    td[3 * i] = (HU_ - prev[3 * i]) * DT_R;                              /* :738-740 */
+    td[3 * i + 1] = (cc_ - prev[3 * i + 1]) * DT_R;
+    td[3 * i + 2] = (fb_ - prev[3 * i + 2]) * DT_R;
+    const double RT_broad_ = rt[3 * i], RT_focus_ = rt[3 * i + 1];
+    double RT_total_ = 0.0;
+    if (day < RT_broad_frac) RT_total_ = RT_broad_ / RT_broad_frac * (day + 1);                                   /* :755 */
+    else if (day < RT_total_frac) RT_total_ = RT_focus_ / RT_focus_frac * ((day + 1) - RT_broad_frac) + RT_broad_; /* :756 */
+    else RT_total_ = RT_broad_ + RT_focus_;
+    rt[3 * i + 2] = RT_total_;
+    if (RT_total_ > RT_total_max) RT_total_max = RT_total_;              /* :761 */
+    prev[3 * i] = soln[0]; prev[3 * i + 1] = soln[1]; prev[3 * i + 2] = soln[2]; /* prev_soln = soln (unclamped), :769 */
+    aux[3 * i] = td[3 * i + 1]; aux[3 * i + 1] = td[3 * i + 2]; aux[3 * i + 2] = RT_total_;
+  }
+  return RT_total_max;
 }
 
 /* check_solution negativity clamp, src/pihna.C:785-790 */

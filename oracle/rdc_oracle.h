@@ -37,6 +37,12 @@ int oracle_assemble_solid_sides(int elem_type, int64_t n_sides, const int64_t* s
                                 const rdc_solid_params* sp, int request_jacobian, const int64_t* row_ptr,
                                 const int32_t* col_idx, double* val, double* rhs);
 void oracle_clamp_nonnegative(double* u, int64_t n);
+int oracle_solid_post_process(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
+                              const double* xyz_undeformed, const double* elem_fibre, const int32_t* elem_material,
+                              const rdc_solid_material* materials, double pseudo_time, double* pressure,
+                              double* von_mises, double* fibre_current);
+double oracle_ripf_check_solution(int64_t n, const rdc_ripf_check_params* p, double* sol, double* prev, double* td,
+                                  double* rt, double* aux);
 #ifdef __cplusplus
 }
 #endif

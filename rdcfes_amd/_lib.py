@@ -46,6 +46,8 @@ SIGNATURES = {
     "rdc_csr_values_device_ptr": (C.c_int, [ctx_p, P(C.c_void_p), P(C.c_void_p)]),
     "rdc_csr_download": (C.c_int, [ctx_p, P(dbl), P(dbl)]),
     "rdc_clamp_nonnegative": (C.c_int, [ctx_p, C.c_int]),
+    "rdc_solid_post_process": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rdc_ripf_check_solution": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_double)]),
     "rdc_timing_enable": (C.c_int, [ctx_p, C.c_int]),
     "rdc_timing_last_ms": (C.c_int, [ctx_p, P(C.c_float)]),
     "rdc_timing_sum_ms": (C.c_int, [ctx_p, P(C.c_float), P(C.c_int)]),

@@ -11,6 +11,7 @@ from .params import HccParams, PihnaParams, RipfParams, SolidMaterial, SolidPara
 TET4, HEX8 = 4, 8
 SCATTER_AUTO, SCATTER_COLOURED, SCATTER_ROWGATHER = 0, 1, 2
 FIELD_OLD_SOLUTION, FIELD_AUX_NODAL, FIELD_UNDEFORMED_XYZ, FIELD_ELEM_FIBRE = 0, 1, 2, 3
+FIELD_PREV_SOLUTION, FIELD_TIME_DERIV, FIELD_RT_DOSE = 4, 5, 6
 VARIANT_AUTO, VARIANT_GENERIC = 0, 1
 
 
@@ -141,6 +142,18 @@ class AssemblyContext:
 
     def clamp_nonnegative(self, field):
         self._ck(self._lib.rdc_clamp_nonnegative(self._h, int(field)))
+
+    def solid_post_process(self, params):
+        """SolidSystem::post_process -> (pressure [ne], von_mises [ne], fibre_current [ne][3])"""
+        pr, vm, fc = np.empty(self.n_elem), np.empty(self.n_elem), np.empty((self.n_elem, 3))
+        self._ck(self._lib.rdc_solid_post_process(self._h, C.byref(params), _dp(pr), _dp(vm), _dp(fc)))
+        return pr, vm, fc
+
+    def ripf_check_solution(self, params):
+        """RIPF check_solution on the device fields (src/ripf.C:675-775); returns the maximum total RT dose."""
+        mx = C.c_double(0.0)
+        self._ck(self._lib.rdc_ripf_check_solution(self._h, C.byref(params), C.byref(mx)))
+        return mx.value
 
     # -- solid set-up
     def solid_set_materials(self, elem_material, materials):

@@ -45,10 +45,11 @@ struct rdc_ctx {
   DevBuf stamps;
   DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab, rg4_nlist, rg4_ploc;
   DevBuf field[RDC_FIELD_COUNT];
-  int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0};
+  int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+  DevBuf wg_max;  // per-workgroup maxima of rdc_ripf_check_solution
   // solid
   DevBuf elem_material, materials, side_elem, side_id, side_disp;
-  DevBuf solid_ke, solid_fe, sg_gptr, sg_gsrc, sg_brow;  // two-pass assembly: element matrices + gather lists
+  DevBuf solid_ke, solid_fe, sg_gptr, sg_gsrc, sg_brow, solid_post;  // two-pass assembly: element matrices + gather lists
   bool solid_gather_ready = false;
   int opt_solid_kernel = 0;  // 0 = two-pass (default), 1 = coloured read-modify-write
   int opt_solid_split = 1;   // two-pass, pass 1: 1 = one thread per element row (default; measured faster), 0 = HEX8 row columns split between two threads
@@ -122,6 +123,9 @@ int64_t field_width(const rdc_ctx* c, int field) {
     case RDC_FIELD_AUX_NODAL: return 3;
     case RDC_FIELD_UNDEFORMED_XYZ: return 3;
     case RDC_FIELD_ELEM_FIBRE: return 3;
+    case RDC_FIELD_PREV_SOLUTION: return c->prep.nvar;
+    case RDC_FIELD_TIME_DERIV: return c->prep.nvar;
+    case RDC_FIELD_RT_DOSE: return 3;
   }
   return 0;
 }
@@ -290,7 +294,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
-                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow};
+                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -679,6 +683,79 @@ int rdc_clamp_nonnegative(rdc_ctx* c, int field) {
     hipLaunchKernelGGL(k_clamp_nonnegative, dim3((unsigned)grid), dim3(256), 0, c->stream, (double*)c->field[field].p, n);
     RDC_HIP(c, hipGetLastError());
   }
+  return RDC_OK;
+}
+
+int rdc_solid_post_process(rdc_ctx* c, const rdc_solid_params* p, double* pressure, double* von_mises,
+                           double* fibre_current) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!p) return fail(c, RDC_ERR_INVALID, "null parameter struct");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (c->prep.nvar != 3) return fail(c, RDC_ERR_INVALID, "solid system needs nvar=3");
+  if (!c->field[RDC_FIELD_UNDEFORMED_XYZ].p) return fail(c, RDC_ERR_STATE, "undeformed coordinates not set");
+  if (!c->field[RDC_FIELD_ELEM_FIBRE].p) return fail(c, RDC_ERR_STATE, "fibre field not set");
+  if (c->n_materials <= 0) return fail(c, RDC_ERR_STATE, "materials not set");
+  int rc = set_device(c);
+  if (rc) return rc;
+  const size_t ne = (size_t)c->prep.n_elem;
+  if ((rc = dev_alloc(c, c->solid_post, ne * 5 * sizeof(double)))) return rc;
+  SolidArgs a{};
+  a.m = mesh_view(c);
+  a.nen = c->prep.nen;
+  a.Xu = (const double*)c->field[RDC_FIELD_UNDEFORMED_XYZ].p;
+  a.fibre = (const double*)c->field[RDC_FIELD_ELEM_FIBRE].p;
+  a.elem_material = (const int32_t*)c->elem_material.p;
+  a.materials = (const rdc_solid_material*)c->materials.p;
+  a.params = *p;
+  a.stream = c->stream;
+  hipError_t e = launch_solid_post(a, (double*)c->solid_post.p);
+  if (e != hipSuccess) return fail(c, RDC_ERR_HIP, "solid post-process launch failed: %s", hipGetErrorString(e));
+  std::vector<double> h(ne * 5);
+  RDC_HIP(c, hipMemcpyAsync(h.data(), c->solid_post.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  for (size_t e2 = 0; e2 < ne; e2++) {
+    if (pressure) pressure[e2] = h[5 * e2];
+    if (von_mises) von_mises[e2] = h[5 * e2 + 1];
+    if (fibre_current) { fibre_current[3 * e2] = h[5 * e2 + 2]; fibre_current[3 * e2 + 1] = h[5 * e2 + 3]; fibre_current[3 * e2 + 2] = h[5 * e2 + 4]; }
+  }
+  return RDC_OK;
+}
+
+int rdc_ripf_check_solution(rdc_ctx* c, const rdc_ripf_check_params* p, double* rt_total_max) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!p) return fail(c, RDC_ERR_INVALID, "null parameter struct");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (c->prep.nvar != 3) return fail(c, RDC_ERR_INVALID, "RIPF check_solution needs nvar=3");
+  if (!(p->time_step > 0.0)) return fail(c, RDC_ERR_INVALID, "time_step must be positive");
+  if (p->RT_broad_fractions < 0 || p->RT_focus_fractions < 0) return fail(c, RDC_ERR_INVALID, "negative fraction count");
+  const int need[] = {RDC_FIELD_OLD_SOLUTION, RDC_FIELD_PREV_SOLUTION, RDC_FIELD_RT_DOSE};
+  const int64_t n = c->prep.n_node;
+  for (int f : need)
+    if (!c->field[f].p || c->field_count[f] != 3 * n) return fail(c, RDC_ERR_STATE, "field %d not set", f);
+  int rc = set_device(c);
+  if (rc) return rc;
+  for (int f : {RDC_FIELD_TIME_DERIV, RDC_FIELD_AUX_NODAL}) {
+    if (c->field[f].p && c->field_count[f] == 3 * n) continue;
+    if (c->field[f].p && !c->field[f].owned) return fail(c, RDC_ERR_STATE, "bound field %d has the wrong size", f);
+    if ((rc = dev_alloc(c, c->field[f], (size_t)(3 * n) * sizeof(double)))) return rc;
+    c->field_count[f] = 3 * n;
+  }
+  int64_t grid = (n + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  if ((rc = dev_alloc(c, c->wg_max, (size_t)grid * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(k_ripf_check, dim3((unsigned)grid), dim3(256), 0, c->stream, n, 1.0 / p->time_step, p->HU_min, p->HU_max,
+                     (double)p->RT_broad_fractions, (double)p->RT_focus_fractions, (int)p->day,
+                     (double*)c->field[RDC_FIELD_OLD_SOLUTION].p, (double*)c->field[RDC_FIELD_PREV_SOLUTION].p,
+                     (double*)c->field[RDC_FIELD_TIME_DERIV].p, (double*)c->field[RDC_FIELD_RT_DOSE].p,
+                     (double*)c->field[RDC_FIELD_AUX_NODAL].p, (double*)c->wg_max.p);
+  RDC_HIP(c, hipGetLastError());
+  std::vector<double> h((size_t)grid);
+  RDC_HIP(c, hipMemcpyAsync(h.data(), c->wg_max.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  double mx = -1.0;
+  for (double v : h) mx = v > mx ? v : mx;
+  if (rt_total_max) *rt_total_max = mx;
   return RDC_OK;
 }
 

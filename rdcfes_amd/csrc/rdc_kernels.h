@@ -155,6 +155,43 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
   for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
 }
 
+// RIPF check_solution (src/ripf.C:675-775): clamp, time-derivative system, fractionation schedule, prev := unclamped,
+// aux record of the next assembly; per-workgroup maxima of the total dose go to wg_max[blockIdx.x].
+static __global__ void __launch_bounds__(256)
+k_ripf_check(int64_t n, double dt_r, double HU_min, double HU_max, double broad_frac, double focus_frac, int day,
+             double* __restrict__ sol, double* __restrict__ prev, double* __restrict__ td, double* __restrict__ rt,
+             double* __restrict__ aux, double* __restrict__ wg_max) {
+  __shared__ double red[256];
+  double mx = -1.0;  // :705
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double s0 = sol[3 * i], s1 = sol[3 * i + 1], s2 = sol[3 * i + 2];
+    double HU = s0, cc = s1, fb = s2;
+    if (HU < HU_min) HU = HU_min; else if (HU > HU_max) HU = HU_max;  // :722
+    if (cc < 0.0) cc = 0.0;
+    if (fb < 0.0) fb = 0.0;
+    const double t0 = (HU - prev[3 * i]) * dt_r, t1 = (cc - prev[3 * i + 1]) * dt_r, t2 = (fb - prev[3 * i + 2]) * dt_r;
+    sol[3 * i] = HU; sol[3 * i + 1] = cc; sol[3 * i + 2] = fb;
+    td[3 * i] = t0; td[3 * i + 1] = t1; td[3 * i + 2] = t2;
+    prev[3 * i] = s0; prev[3 * i + 1] = s1; prev[3 * i + 2] = s2;      // :769 copies the unclamped global solution
+    const double rb = rt[3 * i], rf = rt[3 * i + 1];
+    const double total_frac = broad_frac + focus_frac;
+    double tot;
+    if (day < broad_frac) tot = rb / broad_frac * (day + 1);
+    else if (day < total_frac) tot = rf / focus_frac * ((day + 1) - broad_frac) + rb;
+    else tot = rb + rf;
+    rt[3 * i + 2] = tot;
+    aux[3 * i] = t1; aux[3 * i + 1] = t2; aux[3 * i + 2] = tot;
+    mx = tot > mx ? tot : mx;                                           // std::max(RT_total_max, RT_total_), :761
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x + s] > red[threadIdx.x] ? red[threadIdx.x + s] : red[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) wg_max[blockIdx.x] = red[0];
+}
+
 // check_solution clamp (src/pihna.C:785-790), in place
 static __global__ void k_clamp_nonnegative(double* __restrict__ u, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -32,5 +32,6 @@ struct SolidArgs {
   int gather;                  // pass 2: 0 = stores staged through LDS (runs of consecutive doubles), 1 = 24-byte pieces
 };
 hipError_t launch_solid(const SolidArgs& a);
+hipError_t launch_solid_post(const SolidArgs& a, double* out /* [n_elem][5] device */);
 }  // namespace rdc
 #endif

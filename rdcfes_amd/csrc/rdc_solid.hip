@@ -683,6 +683,90 @@ static void launch_two_pass(const SolidArgs& a) {
                      a.m.pair_elem, a.m.pair_local, a.fe, a.rhs);
 }
 
+// SolidSystem::post_process (src/solid_system.C:394-538): one thread per element.
+// out: [n_elem][5] = {pressure, von Mises, F*eta averaged (3)}
+template <int NEN>
+__global__ void __launch_bounds__(128)
+k_solid_post(const MeshDev m, const double* __restrict__ Xu, const double* __restrict__ fibre,
+             const int32_t* __restrict__ elem_material, const rdc_solid_material* __restrict__ materials,
+             double pseudo_time, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m.n_elem) return;
+  double X[NEN][3], XU[NEN][3];
+#pragma unroll
+  for (int i = 0; i < NEN; i++) {
+    const int64_t n = m.conn[e * NEN + i];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { X[i][d] = m.xyz[3 * n + d]; XU[i][d] = Xu[3 * n + d]; }
+  }
+  const rdc_solid_material mat = materials[elem_material[e]];
+  const double mu = 0.5 * mat.Young / (1.0 + mat.Poisson);
+  const double lame = mat.Young * mat.Poisson / ((1.0 + mat.Poisson) * (1.0 - 2.0 * mat.Poisson));
+  const double K = mat.FibreStiffness;
+  const double eta[3] = {fibre[3 * e], fibre[3 * e + 1], fibre[3 * e + 2]};
+  double A[3] = {0.0, 0.0, 0.0};
+  if (K > 0.0) {
+    const double nrm = sqrt(eta[0] * eta[0] + eta[1] * eta[1] + eta[2] * eta[2]);
+    A[0] = eta[0] / nrm; A[1] = eta[1] / nrm; A[2] = eta[2] / nrm;
+  }
+  const double Kf = (K > 0.0) ? K : 0.0;
+  double lam[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) lam[d] = 1.0 + pseudo_time * mat.rate[d];
+  double sc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, fv[3] = {0.0, 0.0, 0.0};  // 00,11,22,01,12,02
+#pragma unroll 1
+  for (int q = 0; q < Ref<NEN>::NQP; q++) {
+    double N[NEN], G[NEN][3], W;
+    fe_point<NEN>(X, q, N, G, W);
+    double gX[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < NEN; l++) s += G[l][c] * XU[l][d];
+        gX[d][c] = s;
+      }
+    SolidPoint P;
+    solid_point(gX, lam, A, mu, lame, Kf, false, P);
+    sc[0] += P.sigma[0][0]; sc[1] += P.sigma[1][1]; sc[2] += P.sigma[2][2];
+    sc[3] += P.sigma[0][1]; sc[4] += P.sigma[1][2]; sc[5] += P.sigma[0][2];  // upper triangle, :517-519
+    // F = gradX^-1 applied to eta: solve gX f = eta by Cramer's rule
+    const double c00 = gX[1][1] * gX[2][2] - gX[1][2] * gX[2][1];
+    const double c01 = gX[1][2] * gX[2][0] - gX[1][0] * gX[2][2];
+    const double c02 = gX[1][0] * gX[2][1] - gX[1][1] * gX[2][0];
+    const double s = 1.0 / (gX[0][0] * c00 + gX[0][1] * c01 + gX[0][2] * c02);
+    const double F00 = c00 * s, F01 = (gX[0][2] * gX[2][1] - gX[0][1] * gX[2][2]) * s, F02 = (gX[0][1] * gX[1][2] - gX[0][2] * gX[1][1]) * s;
+    const double F10 = c01 * s, F11 = (gX[0][0] * gX[2][2] - gX[0][2] * gX[2][0]) * s, F12 = (gX[0][2] * gX[1][0] - gX[0][0] * gX[1][2]) * s;
+    const double F20 = c02 * s, F21 = (gX[0][1] * gX[2][0] - gX[0][0] * gX[2][1]) * s, F22 = (gX[0][0] * gX[1][1] - gX[0][1] * gX[1][0]) * s;
+    fv[0] += F00 * eta[0] + F01 * eta[1] + F02 * eta[2];
+    fv[1] += F10 * eta[0] + F11 * eta[1] + F12 * eta[2];
+    fv[2] += F20 * eta[0] + F21 * eta[1] + F22 * eta[2];
+  }
+  const double inq = 1.0 / (double)Ref<NEN>::NQP;
+#pragma unroll
+  for (int x = 0; x < 6; x++) sc[x] *= inq;
+  // principal-stress invariants: (e0+e1+e2)/3 = tr/3;  e0^2+e1^2+e2^2-e0e1-e0e2-e1e2 = I1^2 - 3 I2
+  const double dev = sc[0] * sc[0] + sc[1] * sc[1] + sc[2] * sc[2] - sc[0] * sc[1] - sc[0] * sc[2] - sc[1] * sc[2] +
+                     3.0 * (sc[3] * sc[3] + sc[4] * sc[4] + sc[5] * sc[5]);
+  double* o = out + 5 * e;
+  o[0] = (sc[0] + sc[1] + sc[2]) / 3.0;
+  o[1] = sqrt(dev > 0.0 ? dev : 0.0);
+  o[2] = fv[0] * inq; o[3] = fv[1] * inq; o[4] = fv[2] * inq;
+}
+
+hipError_t launch_solid_post(const SolidArgs& a, double* out) {
+  const unsigned grid = (unsigned)((a.m.n_elem + 127) / 128);
+  if (a.nen == 4)
+    hipLaunchKernelGGL((k_solid_post<4>), dim3(grid), dim3(128), 0, a.stream, a.m, a.Xu, a.fibre, a.elem_material, a.materials,
+                       a.params.pseudo_time, out);
+  else
+    hipLaunchKernelGGL((k_solid_post<8>), dim3(grid), dim3(128), 0, a.stream, a.m, a.Xu, a.fibre, a.elem_material, a.materials,
+                       a.params.pseudo_time, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_solid(const SolidArgs& a) {
   if (a.kernel == 0) {
     if (a.nen == 4) launch_two_pass<4>(a); else launch_two_pass<8>(a);

@@ -40,6 +40,12 @@ class SolidParams(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class RipfCheckParams(C.Structure):
+    """rdc_ripf_check_params: what check_solution reads, src/ripf.C:697-703."""
+    _fields_ = [("time_step", _D), ("HU_min", _D), ("HU_max", _D), ("RT_broad_fractions", C.c_int32),
+                ("RT_focus_fractions", C.c_int32), ("day", C.c_int32), ("_pad", C.c_int32)]
+
+
 # reference parameter key -> struct field
 PIHNA_KEYS = {
     "time_step": "time_step",
