@@ -122,7 +122,13 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
   for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
   __syncthreads();
   const int64_t p0 = m.node_pair_ptr[n0], p1 = m.node_pair_ptr[n1];
-  for (int64_t p = p0 + threadIdx.x; p < p1; p += BLOCK) {
+  // The pairs of one node are consecutive in the list and all add into the same diagonal block: consecutive
+  // lanes on consecutive pairs would serialise every ds_add_f64 on that address (8-way on HEX8, 24-way on
+  // TET4; tools/lds_atomic_bench.hip).  Transposed lane mapping: the 16 lanes of an LDS pass take pairs 8
+  // apart, i.e. (mostly) different row nodes, whose rows never share an address.
+  constexpr int GRP = BLOCK / 8;
+  const int64_t tperm = (int64_t)(threadIdx.x % GRP) * 8 + threadIdx.x / GRP;
+  for (int64_t p = p0 + tperm; p < p1; p += BLOCK) {
     const int64_t e = m.pair_elem[p];
     const int i = m.pair_local[p];
     uint32_t nd[NEN];
