@@ -72,6 +72,7 @@ extern "C" {
 #define RDC_FIELD_AUX_NODAL      1  /* [n_nodes][naux]   RIPF: {cc_dtime, fb_dtime, RT_total}          */
 #define RDC_FIELD_UNDEFORMED_XYZ 2  /* [n_nodes][3]      solid: "SolidSystem::auxiliary"               */
 #define RDC_FIELD_ELEM_FIBRE     3  /* [n_elem][3]       solid: fibre direction, vars 0..2 of "::fibre" */
+#define RDC_FIELD_ELEM_TRACTS    3  /* [n_elem][3]       ADPM: the "Tracts" system (src/adpm.C:448-453); same slot as the fibre */
 #define RDC_FIELD_PREV_SOLUTION  4  /* [n_nodes][nvar]   RIPF check_solution: prev_soln (src/ripf.C:675,769)         */
 #define RDC_FIELD_TIME_DERIV     5  /* [n_nodes][nvar]   "RIPF-TimeDeriv" system (src/ripf.C:738-740)                */
 #define RDC_FIELD_RT_DOSE        6  /* [n_nodes][3]      "RT" system {broad, focus, total} (src/ripf.C:749-760)      */
@@ -123,6 +124,29 @@ typedef struct rdc_hcc_params {
 } rdc_hcc_params;
 
 /* per-subdomain material, src/solid_system.C:183-190 */
+/* es.parameters of assemble_adpm, src/adpm.C:367-413 (keys in the comments; defaults src/adpm.C:163-233).
+ * pulse / sigmoid triples = {magnitude, c0, c1}, trapezoid = {magnitude, c0, c1, c2, c3} (src/utils.h:100-187). */
+typedef struct rdc_adpm_params {
+  double time_step;                 /* "time_step"                                             */
+  double time;                      /* system.time: decay/PrP is scaled by pow(time, exponent) */
+  double decay_PrP_time_exponent;   /* "decay/PrP/time_exponent"                               */
+  double decay_PrP[3];              /* "decay/PrP", ".../pulse/0", ".../pulse/1"               */
+  double transform_A_b[5];          /* "transform/A_b", ".../trapezoid/0..3"                   */
+  double transform_Tau[5];          /* "transform/Tau", ".../trapezoid/0..3"                   */
+  double diffuse_A_b[3];            /* "diffuse/A_b", ".../pulse/0,1"                          */
+  double taxis1_A_b[3];             /* "taxis_1/A_b", ".../pulse/0,1"                          */
+  double taxis2_A_b[3];             /* "taxis_2/A_b", ".../pulse/0,1"                          */
+  double produce_A_b[3];            /* "produce/A_b", ".../sigmoid/0,1"                        */
+  double decay_A_b[3];              /* "decay/A_b", ".../pulse/0,1"                            */
+  double diffuse_Tau[3];            /* "diffuse/Tau", ...                                      */
+  double taxis1_Tau[3];             /* "taxis_1/Tau", ...                                      */
+  double taxis2_Tau[3];             /* "taxis_2/Tau", ...                                      */
+  double produce_Tau[3];            /* "produce/Tau", ".../sigmoid/0,1"                        */
+  double decay_Tau[3];              /* "decay/Tau", ...                                        */
+  double taxis_A_b_angle;           /* "taxis/A_b/angle" in RADIANS (input() converts degrees, src/adpm.C:193) */
+  double taxis_Tau_angle;           /* "taxis/Tau/angle" in radians                            */
+} rdc_adpm_params;
+
 typedef struct rdc_solid_material {
   double Young, Poisson, FibreStiffness;
   double rate[3];                      /* VolumetricStretchRatio/rate_0..2 */
@@ -190,6 +214,8 @@ int rdc_solid_set_sides(rdc_ctx* ctx, int64_t n_sides, const int64_t* side_elem,
 int rdc_assemble_pihna(rdc_ctx* ctx, const rdc_pihna_params* p);
 int rdc_assemble_ripf(rdc_ctx* ctx, const rdc_ripf_params* p);
 int rdc_assemble_hcc(rdc_ctx* ctx, const rdc_hcc_params* p);
+/* assemble_adpm, src/adpm.C:324-652: unknowns PrP, A_b, Tau; needs RDC_FIELD_ELEM_TRACTS */
+int rdc_assemble_adpm(rdc_ctx* ctx, const rdc_adpm_params* p);
 /* residual (+ Jacobian if request_jacobian) of the SolidSystem; nvar must be 3 */
 int rdc_solid_assemble(rdc_ctx* ctx, const rdc_solid_params* p, int request_jacobian);
 

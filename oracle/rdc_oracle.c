@@ -647,6 +647,135 @@ void oracle_solid_element(int nen, int nqp, const double* dphi, const double* Jx
   }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * ADPM                                                              src/adpm.C:324-652
+ * piecewise rate functions                                          src/utils.h:100-187
+ * ------------------------------------------------------------------------------------------ */
+static double Pi_(double C, const double* p_) {
+  const double cM = p_[0];
+  if (0.0 >= cM) return 0.0;
+  const double c0 = p_[1], c1 = p_[2];
+  if (C < c0) return 0.0;
+  else if (C < c1) return cM;
+  else return 0.0;
+}
+static double SD_(double C, const double* p_) {
+  const double cM = p_[0];
+  if (0.0 >= cM) return 0.0;
+  const double c0 = p_[1], c1 = p_[2];
+  if (C < c0) return cM;
+  else if (C < c1) return cM * (c1 - C) / (c1 - c0);
+  else return 0.0;
+}
+static double deriv_SD_(double C, const double* p_) {
+  const double cM = p_[0];
+  if (0.0 >= cM) return 0.0;
+  const double c0 = p_[1], c1 = p_[2];
+  if (C < c0) return 0.0;
+  else if (C < c1) return -cM / (c1 - c0);
+  else return 0.0;
+}
+static double Tr_(double C, const double* p_) {
+  const double cM = p_[0];
+  if (0.0 >= cM) return 0.0;
+  const double c0 = p_[1], c1 = p_[2], c2 = p_[3], c3 = p_[4];
+  if (C < c0) return 0.0;
+  else if (C < c1) return cM * (C - c0) / (c1 - c0);
+  else if (C < c2) return cM;
+  else if (C < c3) return cM * (c3 - C) / (c3 - c2);
+  else return 0.0;
+}
+static double deriv_Tr_(double C, const double* p_) {
+  const double cM = p_[0];
+  if (0.0 >= cM) return 0.0;
+  const double c0 = p_[1], c1 = p_[2], c2 = p_[3], c3 = p_[4];
+  if (C < c0) return 0.0;
+  else if (C < c1) return cM / (c1 - c0);
+  else if (C < c2) return 0.0;
+  else if (C < c3) return -cM / (c3 - c2);
+  else return 0.0;
+}
+
+/* u: [nen][3] = (PrP, A_b, Tau); tracts3: the element's tract vector ("Tracts" system, :448-453).
+ * The boundary-penalty block of upstream is dead code (`if ( 0 )`, :601) and is not restated. */
+#define KE(a, b) Ke[((a) * nen + i) * nd + (b) * nen + j]
+#define FE(a) Fe[(a) * nen + i]
+void oracle_adpm_element(int nen, int nqp, const double* phi, const double* dphi, const double* JxW,
+                         const double* u, const double* tracts3, const rdc_adpm_params* P, double* Ke,
+                         double* Fe) {
+  const int nd = 3 * nen;
+  memset(Ke, 0, sizeof(double) * nd * nd);
+  memset(Fe, 0, sizeof(double) * nd);
+  const double DT_2 = P->time_step / 2.0;                                        /* :365 */
+  const double decay_PrP[3] = {P->decay_PrP[0] * pow(P->time, P->decay_PrP_time_exponent), P->decay_PrP[1],
+                               P->decay_PrP[2]};                                 /* :369-372 */
+  const double* diffuse_A_b = P->diffuse_A_b; const double* taxis1_A_b = P->taxis1_A_b;
+  const double* taxis2_A_b = P->taxis2_A_b;   const double* produce_A_b = P->produce_A_b;
+  const double* transform_A_b = P->transform_A_b; const double* decay_A_b = P->decay_A_b;
+  const double* diffuse_Tau = P->diffuse_Tau; const double* taxis1_Tau = P->taxis1_Tau;
+  const double* taxis2_Tau = P->taxis2_Tau;   const double* produce_Tau = P->produce_Tau;
+  const double* transform_Tau = P->transform_Tau; const double* decay_Tau = P->decay_Tau;
+  const double omega_A_b = cos(P->taxis_A_b_angle), omega_Tau = cos(P->taxis_Tau_angle); /* :412-413 */
+  for (int q = 0; q < nqp; q++) {
+    double PrP_old = 0, A_b_old = 0, Tau_old = 0, GA[3] = {0, 0, 0}, GT[3] = {0, 0, 0};
+    for (int l = 0; l < nen; l++) { /* :462-471 */
+      PrP_old += PHI(l) * u[3 * l + 0];
+      A_b_old += PHI(l) * u[3 * l + 1];
+      Tau_old += PHI(l) * u[3 * l + 2];
+      for (int d = 0; d < 3; d++) { GA[d] += DPHI(l, d) * u[3 * l + 1]; GT[d] += DPHI(l, d) * u[3 * l + 2]; }
+    }
+    const double nA = sqrt(GA[0] * GA[0] + GA[1] * GA[1] + GA[2] * GA[2]);
+    const double nT = sqrt(GT[0] * GT[0] + GT[1] * GT[1] + GT[2] * GT[2]);       /* :473 */
+    double tract_A_b[3] = {0, 0, 0}, tract_Tau[3] = {0, 0, 0};
+    if (nA) {                                                                    /* :477-484 */
+      const double d = (GA[0] / nA) * tracts3[0] + (GA[1] / nA) * tracts3[1] + (GA[2] / nA) * tracts3[2];
+      if (d > +omega_A_b) for (int x = 0; x < 3; x++) tract_A_b[x] = tracts3[x];
+      else if (d < -omega_A_b) for (int x = 0; x < 3; x++) tract_A_b[x] = -tracts3[x];
+    }
+    if (nT) {                                                                    /* :485-493 */
+      const double d = (GT[0] / nT) * tracts3[0] + (GT[1] / nT) * tracts3[1] + (GT[2] / nT) * tracts3[2];
+      if (d > +omega_Tau) for (int x = 0; x < 3; x++) tract_Tau[x] = tracts3[x];
+      else if (d < -omega_Tau) for (int x = 0; x < 3; x++) tract_Tau[x] = -tracts3[x];
+    }
+    const double W = JxW[q];
+    for (int i = 0; i < nen; i++) {
+      const double pi = PHI(i);
+      const double gA = dot_dphi(GA, dphi, q, nen, i), gT = dot_dphi(GT, dphi, q, nen, i);
+      const double tA = dot_dphi(tract_A_b, dphi, q, nen, i), tT = dot_dphi(tract_Tau, dphi, q, nen, i);
+      FE(0) += W * (PrP_old * pi                                                  /* :497-504 */
+                    + DT_2 * (-Tr_(A_b_old, transform_A_b) * PrP_old * pi - Tr_(Tau_old, transform_Tau) * PrP_old * pi -
+                              Pi_(PrP_old, decay_PrP) * PrP_old * pi));
+      FE(1) += W * (A_b_old * pi                                                  /* :506-518 */
+                    + DT_2 * (SD_(A_b_old, produce_A_b) * A_b_old * pi + Tr_(A_b_old, transform_A_b) * PrP_old * pi -
+                              Pi_(A_b_old, decay_A_b) * A_b_old * pi - Pi_(A_b_old, diffuse_A_b) * gA -
+                              Pi_(A_b_old, taxis1_A_b) * A_b_old * tA + Pi_(Tau_old, taxis2_A_b) * A_b_old * tT));
+      FE(2) += W * (Tau_old * pi                                                  /* :520-532 */
+                    + DT_2 * (SD_(Tau_old, produce_Tau) * Tau_old * pi + Tr_(Tau_old, transform_Tau) * PrP_old * pi -
+                              Pi_(Tau_old, decay_Tau) * Tau_old * pi - Pi_(Tau_old, diffuse_Tau) * gT -
+                              Pi_(Tau_old, taxis1_Tau) * Tau_old * tT + Pi_(A_b_old, taxis2_Tau) * Tau_old * tA));
+      for (int j = 0; j < nen; j++) {
+        const double pj = PHI(j), pp = pj * pi, dd = dphi_dphi(dphi, q, nen, j, i);
+        KE(0, 0) += W * (pp - DT_2 * (-Tr_(A_b_old, transform_A_b) * pp - Tr_(Tau_old, transform_Tau) * pp -
+                                      Pi_(PrP_old, decay_PrP) * pp));             /* :537-545 */
+        KE(0, 1) += W * (-DT_2 * (-deriv_Tr_(A_b_old, transform_A_b) * PrP_old * pp)); /* :546-550 */
+        KE(0, 2) += W * (-DT_2 * (-deriv_Tr_(Tau_old, transform_Tau) * PrP_old * pp)); /* :551-555 */
+        KE(1, 0) += W * (-DT_2 * (Tr_(A_b_old, transform_A_b) * pp));             /* :557-561 */
+        KE(1, 1) += W * (pp - DT_2 * (SD_(A_b_old, produce_A_b) * pp + deriv_SD_(A_b_old, produce_A_b) * A_b_old * pp +
+                                      deriv_Tr_(A_b_old, transform_A_b) * PrP_old * pp - Pi_(A_b_old, decay_A_b) * pp -
+                                      Pi_(A_b_old, diffuse_A_b) * dd - Pi_(A_b_old, taxis1_A_b) * pj * tA +
+                                      Pi_(Tau_old, taxis2_A_b) * pj * tT));       /* :562-575 */
+        KE(2, 0) += W * (-DT_2 * (Tr_(Tau_old, transform_Tau) * pp));             /* :577-581 */
+        KE(2, 2) += W * (pp - DT_2 * (SD_(Tau_old, produce_Tau) * pp + deriv_SD_(Tau_old, produce_Tau) * Tau_old * pp +
+                                      deriv_Tr_(Tau_old, transform_Tau) * PrP_old * pp - Pi_(Tau_old, decay_Tau) * pp -
+                                      Pi_(Tau_old, diffuse_Tau) * dd - Pi_(Tau_old, taxis1_Tau) * pj * tT +
+                                      Pi_(A_b_old, taxis2_Tau) * pj * tA));       /* :582-595 */
+      }
+    }
+  }
+}
+#undef KE
+#undef FE
+
 /* Eigenvalues of a symmetric 3x3 matrix by cyclic Jacobi rotations.  Upstream calls eigen_decomposition()
  * (src/eig3.C:261-271, Householder tridiagonalisation + QL); only the eigenVALUES are consumed
  * (src/solid_system.C:519-524), and both algorithms deliver them to a few ulp of |A|. */
@@ -888,6 +1017,7 @@ int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, in
       case 0: oracle_pihna_element(nen, nqp, phi, dphi, JxW, U, (const rdc_pihna_params*)params, Ke, Fe); break;
       case 1: oracle_ripf_element(nen, nqp, phi, dphi, JxW, U, A, (const rdc_ripf_params*)params, Ke, Fe); break;
       case 2: oracle_hcc_element(nen, nqp, phi, dphi, JxW, U, (const rdc_hcc_params*)params, Ke, Fe); break;
+      case 4: oracle_adpm_element(nen, nqp, phi, dphi, JxW, U, elem_fibre + 3 * e, (const rdc_adpm_params*)params, Ke, Fe); break;
       case 3: {
         const rdc_solid_params* sp = (const rdc_solid_params*)params;
         oracle_solid_element(nen, nqp, dphi, JxW, XU, elem_fibre + 3 * e, &materials[elem_material[e]],

@@ -26,6 +26,7 @@ SOURCES = [
     "rdc_model_pihna.hip",
     "rdc_model_ripf.hip",
     "rdc_model_hcc.hip",
+    "rdc_model_adpm.hip",
     "rdc_tet4_fast.hip",
     "rdc_solid.hip",
 ]

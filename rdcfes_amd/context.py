@@ -12,6 +12,7 @@ TET4, HEX8 = 4, 8
 SCATTER_AUTO, SCATTER_COLOURED, SCATTER_ROWGATHER = 0, 1, 2
 FIELD_OLD_SOLUTION, FIELD_AUX_NODAL, FIELD_UNDEFORMED_XYZ, FIELD_ELEM_FIBRE = 0, 1, 2, 3
 FIELD_PREV_SOLUTION, FIELD_TIME_DERIV, FIELD_RT_DOSE = 4, 5, 6
+FIELD_ELEM_TRACTS = FIELD_ELEM_FIBRE  # ADPM: same per-element slot
 VARIANT_AUTO, VARIANT_GENERIC = 0, 1
 
 
@@ -181,6 +182,10 @@ class AssemblyContext:
 
     def assemble_hcc(self, p: HccParams):
         self._ck(self._lib.rdc_assemble_hcc(self._h, C.byref(p)))
+
+    def assemble_adpm(self, p):
+        """assemble_adpm (src/adpm.C:324-652); the tract vectors go into FIELD_ELEM_TRACTS first."""
+        self._ck(self._lib.rdc_assemble_adpm(self._h, C.byref(p)))
 
     def solid_assemble(self, p: SolidParams, request_jacobian=True):
         self._ck(self._lib.rdc_solid_assemble(self._h, C.byref(p), 1 if request_jacobian else 0))

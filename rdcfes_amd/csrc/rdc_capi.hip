@@ -197,6 +197,8 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     return fail(c, RDC_ERR_INVALID, "model needs nvar=%d, mesh was uploaded with nvar=%d", nvar_expected, c->prep.nvar);
   if (!c->field[RDC_FIELD_OLD_SOLUTION].p) return fail(c, RDC_ERR_STATE, "old solution field not set");
   if (need_aux && !c->field[RDC_FIELD_AUX_NODAL].p) return fail(c, RDC_ERR_STATE, "aux nodal field not set");
+  if (M::NELEM > 0 && (!c->field[RDC_FIELD_ELEM_TRACTS].p || c->field_count[RDC_FIELD_ELEM_TRACTS] != (int64_t)M::NELEM * c->prep.n_elem))
+    return fail(c, RDC_ERR_STATE, "per-element field (tracts) not set");
   int rc = set_device(c);
   if (rc) return rc;
   const typename M::K k = M::derive(*p);
@@ -208,6 +210,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (rc) return rc;
   a.u = (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p;
   a.aux = (const double*)c->field[RDC_FIELD_AUX_NODAL].p;
+  a.elem = (const double*)c->field[RDC_FIELD_ELEM_TRACTS].p;
   a.packed = (double*)c->packed.p;
   a.variant = c->variant;
   a.opt_occ = c->opt_occ;
@@ -583,6 +586,7 @@ int rdc_solid_set_sides(rdc_ctx* c, int64_t n_sides, const int64_t* side_elem, c
 int rdc_assemble_pihna(rdc_ctx* c, const rdc_pihna_params* p) { return assemble_rd<Pihna>(c, p, 5, false); }
 int rdc_assemble_ripf(rdc_ctx* c, const rdc_ripf_params* p) { return assemble_rd<Ripf>(c, p, 3, true); }
 int rdc_assemble_hcc(rdc_ctx* c, const rdc_hcc_params* p) { return assemble_rd<Hcc>(c, p, 3, false); }
+int rdc_assemble_adpm(rdc_ctx* c, const rdc_adpm_params* p) { return assemble_rd<Adpm>(c, p, 3, false); }
 
 int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobian) {
   if (!c) return RDC_ERR_INVALID;

@@ -96,6 +96,8 @@ struct PihnaK {  // src/pihna.C:358-381
 };
 
 struct Pihna {
+  static constexpr int NELEM = 0;  // per-element input doubles
+  RDC_HD static void grad_post(const PihnaK&, double (*)[3], const double*) {}
   static constexpr int NV = 5, NG = 4, NAUX = 0;
   static constexpr int FAST_EXP_MODE = 3;  // exponent with a dedicated kernel instantiation (shipped value)
   using K = PihnaK;
@@ -274,6 +276,8 @@ struct RipfK {
 };
 
 struct Ripf {
+  static constexpr int NELEM = 0;  // per-element input doubles
+  RDC_HD static void grad_post(const RipfK&, double (*)[3], const double*) {}
   static constexpr int NV = 3, NG = 3, NAUX = 3;
   static constexpr int FAST_EXP_MODE = 25;  // volume_fraction/exponent = 2.5 in run/RIPF133/input.dat
   using K = RipfK;
@@ -406,6 +410,8 @@ struct HccK {
 };
 
 struct Hcc {
+  static constexpr int NELEM = 0;  // per-element input doubles
+  RDC_HD static void grad_post(const HccK&, double (*)[3], const double*) {}
   static constexpr int NV = 3, NG = 1, NAUX = 0;
   static constexpr int FAST_EXP_MODE = 3;
   using K = HccK;
@@ -471,6 +477,157 @@ struct Hcc {
 };
 
 // exponent -> EXP_MODE (0 = general pow)
+// =========================================================================================
+// ADPM (src/adpm.C:324-652): unknowns (PrP, A_b, Tau).  Gradient fields: 0 = grad A_b, 1 = grad Tau,
+// 2 = tract_A_b, 3 = tract_Tau -- the element's tract vector (the "Tracts" system, :448-453) with the sign of
+// its projection on the unit gradient when that exceeds cos(angle), else zero (:474-493); they enter the weak
+// form exactly like gradient fields, so grad_post() writes them into the same slots.
+// Rates are the piecewise functions of src/utils.h:100-187.
+// =========================================================================================
+RDC_HD double pw_Pi(double C, const double* p) {       // rectangular pulse, utils.h:100-110
+  if (0.0 >= p[0]) return 0.0;
+  if (C < p[1]) return 0.0;
+  else if (C < p[2]) return p[0];
+  return 0.0;
+}
+RDC_HD double pw_SD(double C, const double* p) {       // step decay, utils.h:112-122
+  if (0.0 >= p[0]) return 0.0;
+  if (C < p[1]) return p[0];
+  else if (C < p[2]) return p[0] * (p[2] - C) / (p[2] - p[1]);
+  return 0.0;
+}
+RDC_HD double pw_dSD(double C, const double* p) {      // utils.h:123-133
+  if (0.0 >= p[0]) return 0.0;
+  if (C < p[1]) return 0.0;
+  else if (C < p[2]) return -p[0] / (p[2] - p[1]);
+  return 0.0;
+}
+RDC_HD double pw_Tr(double C, const double* p) {       // trapezoid, utils.h:158-172
+  if (0.0 >= p[0]) return 0.0;
+  if (C < p[1]) return 0.0;
+  else if (C < p[2]) return p[0] * (C - p[1]) / (p[2] - p[1]);
+  else if (C < p[3]) return p[0];
+  else if (C < p[4]) return p[0] * (p[4] - C) / (p[4] - p[3]);
+  return 0.0;
+}
+RDC_HD double pw_dTr(double C, const double* p) {      // utils.h:173-187
+  if (0.0 >= p[0]) return 0.0;
+  if (C < p[1]) return 0.0;
+  else if (C < p[2]) return p[0] / (p[2] - p[1]);
+  else if (C < p[3]) return 0.0;
+  else if (C < p[4]) return -p[0] / (p[4] - p[3]);
+  return 0.0;
+}
+
+struct AdpmK {
+  double DT2;
+  double decay_PrP[3], transform_A_b[5], transform_Tau[5];
+  double diffuse_A_b[3], taxis1_A_b[3], taxis2_A_b[3], produce_A_b[3], decay_A_b[3];
+  double diffuse_Tau[3], taxis1_Tau[3], taxis2_Tau[3], produce_Tau[3], decay_Tau[3];
+  double omega_A_b, omega_Tau;  // cos(angle), :412-413
+};
+
+struct Adpm {
+  static constexpr int NELEM = 3;   // tract vector of the element
+  static constexpr int NV = 3, NG = 4, NAUX = 0;
+  static constexpr int FAST_EXP_MODE = 1;  // no power law in this model
+  using K = AdpmK;
+  using C = Coef<NV, NG>;
+  // fields 2, 3 are not gradients of nodal data: any value >= NV makes the evaluators skip them
+  RDC_HD static constexpr int grad_src(int k) { return k == 0 ? 1 : (k == 1 ? 2 : NV); }
+  RDC_HD static constexpr int row_order(int x) { return x; }
+  RDC_HD static constexpr bool hasA(int a, int b) { return (a == 0) || (b == 0) || (a == b); }
+  RDC_HD static constexpr bool hasB(int a, int b, int k) { return a == b && a >= 1 && k >= 2; }
+  RDC_HD static constexpr bool hasD(int a, int b) { return a == b && a >= 1; }
+  RDC_HD static constexpr bool hasRG(int a, int k) { return (a == 1 && k != 1) || (a == 2 && k != 0); }
+
+  static inline K derive(const rdc_adpm_params& p) {
+    K k;
+    k.DT2 = p.time_step / 2.0;                                                    // :365
+    for (int i = 0; i < 3; i++) {
+      k.decay_PrP[i] = p.decay_PrP[i];
+      k.diffuse_A_b[i] = p.diffuse_A_b[i]; k.taxis1_A_b[i] = p.taxis1_A_b[i]; k.taxis2_A_b[i] = p.taxis2_A_b[i];
+      k.produce_A_b[i] = p.produce_A_b[i]; k.decay_A_b[i] = p.decay_A_b[i];
+      k.diffuse_Tau[i] = p.diffuse_Tau[i]; k.taxis1_Tau[i] = p.taxis1_Tau[i]; k.taxis2_Tau[i] = p.taxis2_Tau[i];
+      k.produce_Tau[i] = p.produce_Tau[i]; k.decay_Tau[i] = p.decay_Tau[i];
+    }
+    k.decay_PrP[0] = p.decay_PrP[0] * pow(p.time, p.decay_PrP_time_exponent);     // :369-370
+    for (int i = 0; i < 5; i++) { k.transform_A_b[i] = p.transform_A_b[i]; k.transform_Tau[i] = p.transform_Tau[i]; }
+    k.omega_A_b = cos(p.taxis_A_b_angle);                                         // :412-413
+    k.omega_Tau = cos(p.taxis_Tau_angle);
+    return k;
+  }
+  static inline double exponent(const K&) { return 1.0; }
+
+  RDC_HD static void tract_of(const double (&g)[3], const double* t, double omega, double (&o)[3]) {
+    o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
+    const double nrm = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);             // :473
+    if (nrm != 0.0) {
+      const double d = (g[0] / nrm) * t[0] + (g[1] / nrm) * t[1] + (g[2] / nrm) * t[2];  // :479-481
+      if (d > +omega) { o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; }
+      else if (d < -omega) { o[0] = -t[0]; o[1] = -t[1]; o[2] = -t[2]; }
+    }
+  }
+  RDC_HD static void grad_post(const K& k, double (*GF)[3], const double* ed) {
+    const double gA[3] = {GF[0][0], GF[0][1], GF[0][2]}, gT[3] = {GF[1][0], GF[1][1], GF[1][2]};
+    double tA[3], tT[3];
+    tract_of(gA, ed, k.omega_A_b, tA);
+    tract_of(gT, ed, k.omega_Tau, tT);
+    for (int d = 0; d < 3; d++) { GF[2][d] = tA[d]; GF[3][d] = tT[d]; }
+  }
+
+  struct Pt {
+    double PrP, A_b, Tau;
+    double TrA, dTrA, TrT, dTrT, PiP;
+    double SDA, dSDA, decA, difA, t1A, t2A;
+    double SDT, dSDT, decT, difT, t1T, t2T;
+  };
+
+  template <int EXP_MODE>
+  RDC_HD static void point(const K& k, const double* u, const double* /*aux*/, Pt& s) {
+    s.PrP = u[0]; s.A_b = u[1]; s.Tau = u[2];
+    s.TrA = pw_Tr(s.A_b, k.transform_A_b); s.dTrA = pw_dTr(s.A_b, k.transform_A_b);
+    s.TrT = pw_Tr(s.Tau, k.transform_Tau); s.dTrT = pw_dTr(s.Tau, k.transform_Tau);
+    s.PiP = pw_Pi(s.PrP, k.decay_PrP);
+    s.SDA = pw_SD(s.A_b, k.produce_A_b); s.dSDA = pw_dSD(s.A_b, k.produce_A_b);
+    s.decA = pw_Pi(s.A_b, k.decay_A_b); s.difA = pw_Pi(s.A_b, k.diffuse_A_b);
+    s.t1A = pw_Pi(s.A_b, k.taxis1_A_b); s.t2A = pw_Pi(s.Tau, k.taxis2_A_b);      // taxis_2 of A_b is gated by Tau, :516
+    s.SDT = pw_SD(s.Tau, k.produce_Tau); s.dSDT = pw_dSD(s.Tau, k.produce_Tau);
+    s.decT = pw_Pi(s.Tau, k.decay_Tau); s.difT = pw_Pi(s.Tau, k.diffuse_Tau);
+    s.t1T = pw_Pi(s.Tau, k.taxis1_Tau); s.t2T = pw_Pi(s.A_b, k.taxis2_Tau);      // :530
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    // PrP, :497-504 and :537-556
+    o.R[0] = s.PrP + T * (-s.TrA * s.PrP - s.TrT * s.PrP - s.PiP * s.PrP);
+    o.A[0][0] = 1.0 - T * (-s.TrA - s.TrT - s.PiP);
+    o.A[0][1] = -T * (-s.dTrA * s.PrP);
+    o.A[0][2] = -T * (-s.dTrT * s.PrP);
+    // A_b, :506-518 and :558-577
+    o.R[1] = s.A_b + T * (s.SDA * s.A_b + s.TrA * s.PrP - s.decA * s.A_b);
+    o.RG[1][0] = -T * s.difA;
+    o.RG[1][2] = -T * s.t1A * s.A_b;
+    o.RG[1][3] = T * s.t2A * s.A_b;
+    o.A[1][0] = -T * s.TrA;
+    o.A[1][1] = 1.0 - T * (s.SDA + s.dSDA * s.A_b + s.dTrA * s.PrP - s.decA);
+    o.D[1][1] = T * s.difA;
+    o.B[1][1][2] = T * s.t1A;
+    o.B[1][1][3] = -T * s.t2A;
+    // Tau, :520-532 and :579-598
+    o.R[2] = s.Tau + T * (s.SDT * s.Tau + s.TrT * s.PrP - s.decT * s.Tau);
+    o.RG[2][1] = -T * s.difT;
+    o.RG[2][3] = -T * s.t1T * s.Tau;
+    o.RG[2][2] = T * s.t2T * s.Tau;
+    o.A[2][0] = -T * s.TrT;
+    o.A[2][2] = 1.0 - T * (s.SDT + s.dSDT * s.Tau + s.dTrT * s.PrP - s.decT);
+    o.D[2][2] = T * s.difT;
+    o.B[2][2][3] = T * s.t1T;
+    o.B[2][2][2] = -T * s.t2T;
+  }
+};
+
 static inline int exp_mode_of(double e) {
   if (e == 1.0) return 1;
   if (e == 2.0) return 2;

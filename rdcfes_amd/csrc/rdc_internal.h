@@ -36,6 +36,7 @@ struct LaunchArgs {
   int nen, exp_mode, strategy;
   const double* u;
   const double* aux;
+  const double* elem = nullptr;  // per-element inputs ([n_elem][M::NELEM]) of models that have them (ADPM tracts)
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
   int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf;  // tuning knobs (rdc_set_option)

@@ -60,8 +60,8 @@ __device__ __forceinline__ void load_element(const MeshDev& m, int64_t e, const 
 template <class M, int NEN, int EXP_MODE>
 __global__ void __launch_bounds__(256)
 k_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count,
-           const double* __restrict__ u, const double* __restrict__ aux, double* __restrict__ val,
-           double* __restrict__ rhs) {
+           const double* __restrict__ u, const double* __restrict__ aux, const double* __restrict__ elem,
+           double* __restrict__ val, double* __restrict__ rhs) {
   constexpr int NV = M::NV;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
@@ -76,7 +76,7 @@ k_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count,
     const int64_t I = m.conn[e * NEN + i];
     if (I >= m.n_owned) continue;  // row assembled by the owner partition
     double acc[NV][NV][NEN], fe[NV];
-    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe);
+    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe, M::NELEM > 0 ? elem + e * M::NELEM : nullptr);
     const int64_t b0 = m.bptr[I];
     const int64_t len = m.bptr[I + 1] - b0;
     double* row = val + (int64_t)NV * NV * b0;
@@ -110,7 +110,8 @@ k_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count,
 template <class M, int NEN, int EXP_MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u,
-            const double* __restrict__ aux, double* __restrict__ val, double* __restrict__ rhs) {
+            const double* __restrict__ aux, const double* __restrict__ elem, double* __restrict__ val,
+            double* __restrict__ rhs) {
   constexpr int NV = M::NV;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int w = blockIdx.x;
@@ -135,7 +136,7 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
     double X[NEN][3], U[NEN][NV], AX[NEN][M::NAUX > 0 ? M::NAUX : 1];
     load_element<M, NEN>(m, e, u, aux, nd, X, U, AX);
     double acc[NV][NV][NEN], fe[NV];
-    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe);
+    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe, M::NELEM > 0 ? elem + e * M::NELEM : nullptr);
     const int64_t I = m.conn[e * NEN + i];
     const int64_t b0 = m.bptr[I];
     const int len = (int)(m.bptr[I + 1] - b0);

@@ -13,7 +13,7 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
     constexpr int BLOCK = 256;
     if (a.n_wg > 0)
       hipLaunchKernelGGL((k_rowgather<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), a.lds_bytes,
-                         a.stream, a.m, k, a.u, a.aux, a.val, a.rhs);
+                         a.stream, a.m, k, a.u, a.aux, a.elem, a.val, a.rhs);
     return hipGetLastError();
   }
   // coloured: one launch per colour, stream order is the only synchronisation needed
@@ -23,14 +23,16 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
     const int block = 256;
     const int64_t grid = (count + block - 1) / block;
     hipLaunchKernelGGL((k_coloured<M, NEN, EXP_MODE>), dim3((unsigned)grid), dim3(block), 0, a.stream, a.m, k,
-                       first, count, a.u, a.aux, a.val, a.rhs);
+                       first, count, a.u, a.aux, a.elem, a.val, a.rhs);
   }
   return hipGetLastError();
 }
 
 template <class M>
 hipError_t launch_rd(const LaunchArgs& a, const typename M::K& k) {
-  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC) return launch_tet4_fast<M>(a, k);
+  if constexpr (M::NELEM == 0) {  // the factored TET4 kernels carry no per-element inputs
+    if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC) return launch_tet4_fast<M>(a, k);
+  }
   if (a.nen == 4) {
     if (a.exp_mode == M::FAST_EXP_MODE) return launch_rd_impl<M, 4, M::FAST_EXP_MODE>(a, k);
     return launch_rd_impl<M, 4, 0>(a, k);

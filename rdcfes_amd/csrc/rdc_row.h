@@ -13,7 +13,8 @@ template <class M, int NEN, int EXP_MODE>
 RDC_HD void rd_row(const typename M::K& k, const double (&X)[NEN][3],
                                        const double (&U)[NEN][M::NV],
                                        const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int irow,
-                                       double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV]) {
+                                       double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV],
+                                       const double* ED = nullptr /* M::NELEM per-element inputs */) {
   constexpr int NV = M::NV, NG = M::NG, NA = (M::NAUX > 0 ? M::NAUX : 1);
 #pragma unroll
   for (int a = 0; a < NV; a++) {
@@ -46,11 +47,12 @@ RDC_HD void rd_row(const typename M::K& k, const double (&X)[NEN][3],
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       const int src = M::grad_src(g);
+      if (src >= NV) { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; continue; }  // filled by grad_post()
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         double s = 0.0;
 #pragma unroll
-        for (int l = 0; l < NEN; l++) s += G[l][d] * (src >= 0 ? U[l][src >= 0 ? src : 0] : AX[l][src < 0 ? (-1 - src) % NA : 0]);
+        for (int l = 0; l < NEN; l++) s += G[l][d] * (src >= 0 ? U[l][(src >= 0 && src < NV) ? src : 0] : AX[l][src < 0 ? (-1 - src) % NA : 0]);
         GF[g][d] = s;
       }
       if (src < 0) {  // RIPF: unit radiotherapy gradient (src/ripf.C:481-484)
@@ -59,6 +61,7 @@ RDC_HD void rd_row(const typename M::K& k, const double (&X)[NEN][3],
         else { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; }
       }
     }
+    if (M::NELEM > 0) M::grad_post(k, GF, ED);
     typename M::Pt pt;
     M::template point<EXP_MODE>(k, uq, aq, pt);
     typename M::C c;

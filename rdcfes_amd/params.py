@@ -40,6 +40,15 @@ class SolidParams(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class AdpmParams(C.Structure):
+    """rdc_adpm_params, src/adpm.C:365-413."""
+    _fields_ = [("time_step", _D), ("time", _D), ("decay_PrP_time_exponent", _D), ("decay_PrP", _D * 3),
+                ("transform_A_b", _D * 5), ("transform_Tau", _D * 5), ("diffuse_A_b", _D * 3), ("taxis1_A_b", _D * 3),
+                ("taxis2_A_b", _D * 3), ("produce_A_b", _D * 3), ("decay_A_b", _D * 3), ("diffuse_Tau", _D * 3),
+                ("taxis1_Tau", _D * 3), ("taxis2_Tau", _D * 3), ("produce_Tau", _D * 3), ("decay_Tau", _D * 3),
+                ("taxis_A_b_angle", _D), ("taxis_Tau_angle", _D)]
+
+
 class RipfCheckParams(C.Structure):
     """rdc_ripf_check_params: what check_solution reads, src/ripf.C:697-703."""
     _fields_ = [("time_step", _D), ("HU_min", _D), ("HU_max", _D), ("RT_broad_fractions", C.c_int32),
@@ -119,3 +128,48 @@ def ripf_params_from_dict(d):
 
 def hcc_params_from_dict(d):
     return _from_dict(HccParams, HCC_KEYS, HCC_DEFAULTS, d)
+
+
+# ADPM: reference key -> (struct field, index); defaults of input(), src/adpm.C:163-233
+def _adpm_keys():
+    keys = {"time_step": ("time_step", None), "decay/PrP/time_exponent": ("decay_PrP_time_exponent", None),
+            "taxis/A_b/angle": ("taxis_A_b_angle", None), "taxis/Tau/angle": ("taxis_Tau_angle", None)}
+    defaults = {"time_step": 1.0e-9, "decay/PrP/time_exponent": 0.0, "taxis/A_b/angle": 89.9, "taxis/Tau/angle": 89.9}
+    def triple(key, field, kind, d0, d1):
+        keys[key] = (field, 0); defaults[key] = 0.0
+        keys[f"{key}/{kind}/0"] = (field, 1); defaults[f"{key}/{kind}/0"] = d0
+        keys[f"{key}/{kind}/1"] = (field, 2); defaults[f"{key}/{kind}/1"] = d1
+    triple("decay/PrP", "decay_PrP", "pulse", -1.0e-20, +1.0e+20)
+    for sp in ("A_b", "Tau"):
+        keys[f"transform/{sp}"] = (f"transform_{sp}", 0); defaults[f"transform/{sp}"] = 0.0
+        for i, d in enumerate((-1.1e-20, -1.0e-20, +1.0e+20, +1.1e+20)):
+            keys[f"transform/{sp}/trapezoid/{i}"] = (f"transform_{sp}", i + 1); defaults[f"transform/{sp}/trapezoid/{i}"] = d
+        triple(f"diffuse/{sp}", f"diffuse_{sp}", "pulse", -1.0e-20, +1.0e+20)
+        triple(f"taxis_1/{sp}", f"taxis1_{sp}", "pulse", -1.0e-20, +1.0e+20)
+        triple(f"taxis_2/{sp}", f"taxis2_{sp}", "pulse", -1.0e-20, +1.0e+20)
+        triple(f"produce/{sp}", f"produce_{sp}", "sigmoid", +1.0e+20, +1.1e+20)
+        triple(f"decay/{sp}", f"decay_{sp}", "pulse", -1.0e-20, +1.0e+20)
+    return keys, defaults
+
+
+ADPM_KEYS, ADPM_DEFAULTS = _adpm_keys()
+
+
+def adpm_params_from_dict(d, time=0.0):
+    """Reference-keyed dict -> AdpmParams.  The two angles are given in DEGREES as in the input file
+    (input() converts them, src/adpm.C:193,215); `time` is system.time of the step being assembled."""
+    import math
+    unknown = set(d) - set(ADPM_KEYS)
+    if unknown:
+        raise KeyError(f"unknown ADPM parameter keys: {sorted(unknown)}")
+    p = AdpmParams()
+    p.time = float(time)
+    for key, (field, idx) in ADPM_KEYS.items():
+        v = float(d.get(key, ADPM_DEFAULTS[key]))
+        if key.endswith("/angle"):
+            v = math.radians(v)
+        if idx is None:
+            setattr(p, field, v)
+        else:
+            getattr(p, field)[idx] = v
+    return p

@@ -141,9 +141,50 @@ def hcc_param_dict(variant="full"):
     return d
 
 
+def adpm_param_dict(variant="shipped"):
+    """run/HCP102513/input.dat as the code reads it: its `taxis/A_b*`, `taxis/Tau*` keys are not the
+    `taxis_1/...`, `taxis_2/...` keys of input() (src/adpm.C:194-199,216-221), so the shipped run has no taxis;
+    'full' switches every term on with thresholds inside the range of adpm_fields()."""
+    d = {"time_step": 0.05, "decay/PrP": 1.0e-4, "decay/PrP/pulse/0": 0.01, "decay/PrP/pulse/1": 10.0,
+         "decay/Tau": 10.0, "decay/Tau/pulse/0": 0.0005}
+    if variant == "full":
+        d.update({"decay/PrP/time_exponent": 0.5,
+                  "transform/A_b": 0.3, "transform/A_b/trapezoid/0": 0.001, "transform/A_b/trapezoid/1": 0.006,
+                  "transform/A_b/trapezoid/2": 0.012, "transform/A_b/trapezoid/3": 0.018,
+                  "transform/Tau": 0.2, "transform/Tau/trapezoid/0": 0.002, "transform/Tau/trapezoid/1": 0.005,
+                  "transform/Tau/trapezoid/2": 0.010, "transform/Tau/trapezoid/3": 0.019,
+                  "diffuse/A_b": 0.02, "diffuse/A_b/pulse/0": 0.002, "diffuse/A_b/pulse/1": 0.5,
+                  "taxis/A_b/angle": 60.0, "taxis_1/A_b": 0.4, "taxis_1/A_b/pulse/0": 0.001, "taxis_1/A_b/pulse/1": 0.015,
+                  "taxis_2/A_b": 0.1, "taxis_2/A_b/pulse/0": 0.004, "taxis_2/A_b/pulse/1": 0.5,
+                  "produce/A_b": 0.7, "produce/A_b/sigmoid/0": 0.005, "produce/A_b/sigmoid/1": 0.015,
+                  "decay/A_b": 0.5, "decay/A_b/pulse/0": 0.008, "decay/A_b/pulse/1": 0.5,
+                  "diffuse/Tau": 0.03, "diffuse/Tau/pulse/0": 0.001, "diffuse/Tau/pulse/1": 0.5,
+                  "taxis/Tau/angle": 45.0, "taxis_1/Tau": 0.3, "taxis_1/Tau/pulse/0": 0.002, "taxis_1/Tau/pulse/1": 0.5,
+                  "taxis_2/Tau": 0.2, "taxis_2/Tau/pulse/0": 0.003, "taxis_2/Tau/pulse/1": 0.012,
+                  "produce/Tau": 0.6, "produce/Tau/sigmoid/0": 0.004, "produce/Tau/sigmoid/1": 0.016})
+    elif variant != "shipped":
+        raise ValueError(variant)
+    return d
+
+
 # ---------------------------------------------------------------------------------------------
 # fields
 # ---------------------------------------------------------------------------------------------
+def adpm_fields(xyz, n_elem, seed=SEED):
+    """([n_node][3] (PrP, A_b, Tau), [n_elem][3] tract vectors): PrP around the shipped background 1
+    (run/HCP102513/Brain_Model_Initial_Nodal_Field.dat), misfolded species in [0, 0.02] with smooth parts so
+    that their gradients have a direction; tracts with the magnitude of the shipped elemental file (~0.1)."""
+    rng = np.random.default_rng(seed + 7)
+    n = xyz.shape[0]
+    u = np.empty((n, 3))
+    u[:, 0] = rng.uniform(0.5, 1.5, n)
+    u[:, 1] = 0.01 + 0.008 * np.sin(5.0 * xyz[:, 0] + 1.0) * np.cos(3.0 * xyz[:, 1]) + rng.uniform(-0.002, 0.002, n)
+    u[:, 2] = 0.01 + 0.008 * np.cos(4.0 * xyz[:, 2] + 0.5) * np.sin(6.0 * xyz[:, 0]) + rng.uniform(-0.002, 0.002, n)
+    tracts = 0.1 * rng.standard_normal((n_elem, 3))
+    return u, tracts
+
+
+
 def pihna_fields(xyz, seed=SEED):
     """[n_node][5] (n,c,h,v,a): background (0,0,0,7170,0) as run/PIHNA/Brain_Model_Initial_Nodal_Field.dat,
     a non-degenerate tumour state inside a sphere r=0.25 (v > 0 everywhere: the 0/0 path of

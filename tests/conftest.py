@@ -110,9 +110,10 @@ def make_prep(shim):
     return f
 
 
-def shim_rows(lib, model, nen, params, X, U, A=None, fast=False, force_general_pow=False):
+def shim_rows(lib, model, nen, params, X, U, A=None, fast=False, force_general_pow=False, elem_data=None):
     """all rows through the product's row function -> (Ke [nv*nen][nv*nen] var-major, Fe)"""
-    nv = {0: 5, 1: 3, 2: 3, 3: 5}[model]
+    nv = {0: 5, 1: 3, 2: 3, 3: 5, 4: 3}[model]
+    ED = None if elem_data is None else np.ascontiguousarray(elem_data, dtype=np.float64)
     X = np.ascontiguousarray(X, dtype=np.float64)
     U = np.ascontiguousarray(U, dtype=np.float64)
     A = None if A is None else np.ascontiguousarray(A, dtype=np.float64)
@@ -123,7 +124,7 @@ def shim_rows(lib, model, nen, params, X, U, A=None, fast=False, force_general_p
         acc = np.empty((nv, nv, nen))
         fe = np.empty(nv)
         rc = lib.shim_row(model, nen, int(fast), int(force_general_pow), C.byref(params), dp(X), dp(U), dp(A), i,
-                          dp(acc), dp(fe))
+                          dp(acc), dp(fe), dp(ED))
         assert rc == 0
         for a in range(nv):
             Fe[a * nen + i] = fe[a]

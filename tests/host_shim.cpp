@@ -15,7 +15,7 @@ namespace {
 
 template <class M, int NEN, int EM>
 void row_generic(const typename M::K& k, const double* Xp, const double* Up, const double* Ap, int irow, double* acc,
-                 double* fe) {
+                 double* fe, const double* ED) {
   constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
   double X[NEN][3], U[NEN][NV], AX[NEN][NA];
   for (int i = 0; i < NEN; i++) {
@@ -24,7 +24,7 @@ void row_generic(const typename M::K& k, const double* Xp, const double* Up, con
     for (int v = 0; v < NA; v++) AX[i][v] = (M::NAUX > 0 && Ap) ? Ap[M::NAUX * i + v] : 0.0;
   }
   double a[NV][NV][NEN], f[NV];
-  rd_row<M, NEN, EM>(k, X, U, AX, irow, a, f);
+  rd_row<M, NEN, EM>(k, X, U, AX, irow, a, f, ED);
   std::memcpy(acc, a, sizeof(a));
   std::memcpy(fe, f, sizeof(f));
 }
@@ -61,20 +61,23 @@ void row_fast(const typename M::K& k, const double* Xp, const double* Up, const 
 
 template <class M, class P>
 int run(const P* p, int nen, int fast, int force_general_pow, const double* X, const double* U, const double* A,
-        int irow, double* acc, double* fe) {
+        int irow, double* acc, double* fe, const double* ED = nullptr) {
   const typename M::K k = M::derive(*p);
   // the dedicated-exponent instantiation the product would pick (Pihna/Hcc: 3, Ripf: 2.5 via sqrt)
   constexpr int FE = M::FAST_EXP_MODE;
   const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == FE;
   if (fast) {
-    if (nen != 4) return 1;
-    if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe); else row_fast<M, 0>(k, X, U, A, irow, acc, fe);
-    return 0;
+    if constexpr (M::NELEM > 0) return 4;  // the factored TET4 row carries no per-element inputs
+    else {
+      if (nen != 4) return 1;
+      if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe); else row_fast<M, 0>(k, X, U, A, irow, acc, fe);
+      return 0;
+    }
   }
   if (nen == 4) {
-    if (cube) row_generic<M, 4, FE>(k, X, U, A, irow, acc, fe); else row_generic<M, 4, 0>(k, X, U, A, irow, acc, fe);
+    if (cube) row_generic<M, 4, FE>(k, X, U, A, irow, acc, fe, ED); else row_generic<M, 4, 0>(k, X, U, A, irow, acc, fe, ED);
   } else if (nen == 8) {
-    if (cube) row_generic<M, 8, FE>(k, X, U, A, irow, acc, fe); else row_generic<M, 8, 0>(k, X, U, A, irow, acc, fe);
+    if (cube) row_generic<M, 8, FE>(k, X, U, A, irow, acc, fe, ED); else row_generic<M, 8, 0>(k, X, U, A, irow, acc, fe, ED);
   } else return 1;
   return 0;
 }
@@ -109,10 +112,11 @@ std::string g_err;
 
 extern "C" {
 
-// model: 0 PIHNA, 1 RIPF, 2 HCC.  acc: [NV][NV][nen] (a, b, column node j in ORIGINAL local order)
+// model: 0 PIHNA, 1 RIPF, 2 HCC, 4 ADPM (ED = tract vector).  acc: [NV][NV][nen] (a, b, column node j in ORIGINAL local order)
 int shim_row(int model, int nen, int fast, int force_general_pow, const void* params, const double* X, const double* U,
-             const double* A, int irow, double* acc, double* fe) {
+             const double* A, int irow, double* acc, double* fe, const double* ED) {
   switch (model) {
+    case 4: return run<Adpm>((const rdc_adpm_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe, ED);
     case 0: return run<Pihna>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
     case 1: return run<Ripf>((const rdc_ripf_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
     case 2: return run<Hcc>((const rdc_hcc_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
@@ -130,6 +134,7 @@ int shim_masks(int model, const void* params, const double* u, const double* aux
     case 1: return masks<Ripf>((const rdc_ripf_params*)params, u, aux, worst);
     case 2: return masks<Hcc>((const rdc_hcc_params*)params, u, aux, worst);
     case 3: return masks<PihnaNoCellTransport>((const rdc_pihna_params*)params, u, aux, worst);
+    case 4: return masks<Adpm>((const rdc_adpm_params*)params, u, aux, worst);
   }
   return 2;
 }
