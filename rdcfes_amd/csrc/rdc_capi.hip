@@ -44,6 +44,8 @@ struct rdc_ctx {
   DevBuf val, rhs, packed;
   DevBuf stamps;
   DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab, rg4_nlist, rg4_ploc;
+  DevBuf rg5_eid;             // pair -> element list, uploaded at the first assembly of a model with per-element inputs
+  bool rg5_eid_ready = false;
   DevBuf field[RDC_FIELD_COUNT];
   int64_t field_count[RDC_FIELD_COUNT] = {0, 0, 0, 0, 0, 0, 0};
   DevBuf wg_max;  // per-workgroup maxima of rdc_ripf_check_solution
@@ -234,6 +236,13 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
       a.rg2.nlist = (const uint32_t*)c->rg4_nlist.p;
       a.rg2.pair_loc = (const uint32_t*)c->rg4_ploc.p;
       a.rg2.nl_stride = c->prep.rg4_nl_stride;
+      if (M::NELEM > 0 && !c->prep.pair_eid.empty()) {
+        if (!c->rg5_eid_ready) {
+          if ((rc = dev_upload(c, c->rg5_eid, c->prep.pair_eid))) return rc;
+          c->rg5_eid_ready = true;
+        }
+        a.rg2.pair_eid = (const uint32_t*)c->rg5_eid.p;
+      }
     }
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
     a.rg2.block = c->prep.rg2_block;
@@ -295,7 +304,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
-                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc,
+                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg5_eid,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
                    &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post};
   for (DevBuf* b : all) dev_free(c, *b);
@@ -419,6 +428,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   c->n_materials = 0; c->n_sides = 0;
   c->have_mesh = true;
   c->solid_gather_ready = false;
+  c->rg5_eid_ready = false;
   return RDC_OK;
 }
 

@@ -490,32 +490,33 @@ RDC_HD double pw_Pi(double C, const double* p) {       // rectangular pulse, uti
   else if (C < p[2]) return p[0];
   return 0.0;
 }
-RDC_HD double pw_SD(double C, const double* p) {       // step decay, utils.h:112-122
+// the ramps divide by a constant width: iw = magnitude / width is formed once on the host (<= 1 ulp off the quotient)
+RDC_HD double pw_SD(double C, const double* p, double iw) {       // step decay, utils.h:112-122
   if (0.0 >= p[0]) return 0.0;
   if (C < p[1]) return p[0];
-  else if (C < p[2]) return p[0] * (p[2] - C) / (p[2] - p[1]);
+  else if (C < p[2]) return (p[2] - C) * iw;
   return 0.0;
 }
-RDC_HD double pw_dSD(double C, const double* p) {      // utils.h:123-133
+RDC_HD double pw_dSD(double C, const double* p, double iw) {      // utils.h:123-133
   if (0.0 >= p[0]) return 0.0;
   if (C < p[1]) return 0.0;
-  else if (C < p[2]) return -p[0] / (p[2] - p[1]);
+  else if (C < p[2]) return -iw;
   return 0.0;
 }
-RDC_HD double pw_Tr(double C, const double* p) {       // trapezoid, utils.h:158-172
+RDC_HD double pw_Tr(double C, const double* p, double iw_up, double iw_dn) {   // trapezoid, utils.h:158-172
   if (0.0 >= p[0]) return 0.0;
   if (C < p[1]) return 0.0;
-  else if (C < p[2]) return p[0] * (C - p[1]) / (p[2] - p[1]);
+  else if (C < p[2]) return (C - p[1]) * iw_up;
   else if (C < p[3]) return p[0];
-  else if (C < p[4]) return p[0] * (p[4] - C) / (p[4] - p[3]);
+  else if (C < p[4]) return (p[4] - C) * iw_dn;
   return 0.0;
 }
-RDC_HD double pw_dTr(double C, const double* p) {      // utils.h:173-187
+RDC_HD double pw_dTr(double C, const double* p, double iw_up, double iw_dn) {  // utils.h:173-187
   if (0.0 >= p[0]) return 0.0;
   if (C < p[1]) return 0.0;
-  else if (C < p[2]) return p[0] / (p[2] - p[1]);
+  else if (C < p[2]) return iw_up;
   else if (C < p[3]) return 0.0;
-  else if (C < p[4]) return -p[0] / (p[4] - p[3]);
+  else if (C < p[4]) return -iw_dn;
   return 0.0;
 }
 
@@ -525,6 +526,7 @@ struct AdpmK {
   double diffuse_A_b[3], taxis1_A_b[3], taxis2_A_b[3], produce_A_b[3], decay_A_b[3];
   double diffuse_Tau[3], taxis1_Tau[3], taxis2_Tau[3], produce_Tau[3], decay_Tau[3];
   double omega_A_b, omega_Tau;  // cos(angle), :412-413
+  double iw_prodA, iw_prodT, iw_trA_up, iw_trA_dn, iw_trT_up, iw_trT_dn;  // magnitude / ramp width
 };
 
 struct Adpm {
@@ -555,6 +557,12 @@ struct Adpm {
     for (int i = 0; i < 5; i++) { k.transform_A_b[i] = p.transform_A_b[i]; k.transform_Tau[i] = p.transform_Tau[i]; }
     k.omega_A_b = cos(p.taxis_A_b_angle);                                         // :412-413
     k.omega_Tau = cos(p.taxis_Tau_angle);
+    k.iw_prodA = k.produce_A_b[0] / (k.produce_A_b[2] - k.produce_A_b[1]);
+    k.iw_prodT = k.produce_Tau[0] / (k.produce_Tau[2] - k.produce_Tau[1]);
+    k.iw_trA_up = k.transform_A_b[0] / (k.transform_A_b[2] - k.transform_A_b[1]);
+    k.iw_trA_dn = k.transform_A_b[0] / (k.transform_A_b[4] - k.transform_A_b[3]);
+    k.iw_trT_up = k.transform_Tau[0] / (k.transform_Tau[2] - k.transform_Tau[1]);
+    k.iw_trT_dn = k.transform_Tau[0] / (k.transform_Tau[4] - k.transform_Tau[3]);
     return k;
   }
   static inline double exponent(const K&) { return 1.0; }
@@ -563,7 +571,8 @@ struct Adpm {
     o[0] = 0.0; o[1] = 0.0; o[2] = 0.0;
     const double nrm = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);             // :473
     if (nrm != 0.0) {
-      const double d = (g[0] / nrm) * t[0] + (g[1] / nrm) * t[1] + (g[2] / nrm) * t[2];  // :479-481
+      const double in = rcp(nrm);
+      const double d = (g[0] * in) * t[0] + (g[1] * in) * t[1] + (g[2] * in) * t[2];  // :479-481
       if (d > +omega) { o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; }
       else if (d < -omega) { o[0] = -t[0]; o[1] = -t[1]; o[2] = -t[2]; }
     }
@@ -586,13 +595,13 @@ struct Adpm {
   template <int EXP_MODE>
   RDC_HD static void point(const K& k, const double* u, const double* /*aux*/, Pt& s) {
     s.PrP = u[0]; s.A_b = u[1]; s.Tau = u[2];
-    s.TrA = pw_Tr(s.A_b, k.transform_A_b); s.dTrA = pw_dTr(s.A_b, k.transform_A_b);
-    s.TrT = pw_Tr(s.Tau, k.transform_Tau); s.dTrT = pw_dTr(s.Tau, k.transform_Tau);
+    s.TrA = pw_Tr(s.A_b, k.transform_A_b, k.iw_trA_up, k.iw_trA_dn); s.dTrA = pw_dTr(s.A_b, k.transform_A_b, k.iw_trA_up, k.iw_trA_dn);
+    s.TrT = pw_Tr(s.Tau, k.transform_Tau, k.iw_trT_up, k.iw_trT_dn); s.dTrT = pw_dTr(s.Tau, k.transform_Tau, k.iw_trT_up, k.iw_trT_dn);
     s.PiP = pw_Pi(s.PrP, k.decay_PrP);
-    s.SDA = pw_SD(s.A_b, k.produce_A_b); s.dSDA = pw_dSD(s.A_b, k.produce_A_b);
+    s.SDA = pw_SD(s.A_b, k.produce_A_b, k.iw_prodA); s.dSDA = pw_dSD(s.A_b, k.produce_A_b, k.iw_prodA);
     s.decA = pw_Pi(s.A_b, k.decay_A_b); s.difA = pw_Pi(s.A_b, k.diffuse_A_b);
     s.t1A = pw_Pi(s.A_b, k.taxis1_A_b); s.t2A = pw_Pi(s.Tau, k.taxis2_A_b);      // taxis_2 of A_b is gated by Tau, :516
-    s.SDT = pw_SD(s.Tau, k.produce_Tau); s.dSDT = pw_dSD(s.Tau, k.produce_Tau);
+    s.SDT = pw_SD(s.Tau, k.produce_Tau, k.iw_prodT); s.dSDT = pw_dSD(s.Tau, k.produce_Tau, k.iw_prodT);
     s.decT = pw_Pi(s.Tau, k.decay_Tau); s.difT = pw_Pi(s.Tau, k.diffuse_Tau);
     s.t1T = pw_Pi(s.Tau, k.taxis1_Tau); s.t2T = pw_Pi(s.A_b, k.taxis2_Tau);      // :530
   }

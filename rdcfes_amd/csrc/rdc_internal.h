@@ -25,6 +25,7 @@ struct Rg2Dev {
   const uint16_t* node_tab = nullptr;
   const uint32_t* nlist = nullptr;
   const uint32_t* pair_loc = nullptr;
+  const uint32_t* pair_eid = nullptr;   // element of the pair (models with per-element inputs only)
   int nl_stride = 0;
   size_t lds_bytes = 0;
   int block = 256;

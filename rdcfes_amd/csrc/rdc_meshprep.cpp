@@ -247,6 +247,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
       const int stride = (nen * nvar + 1) | 1;
       P.wg2.resize((size_t)nwg);
       P.pair_rec.assign((size_t)nwg * block * nen, 0xFFFFFFFFu);
+      if (nen == 4) P.pair_eid.assign((size_t)nwg * block, 0u);
       if (nen == 4) P.pair_aux.assign((size_t)nwg * block * 8, 0);
       P.node_tab.assign((size_t)n_owned * 4, 0);
       P.sdesc.resize((size_t)P.bptr[n_owned]);
@@ -389,6 +390,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
           const std::array<int, 4>& cols = col_of[(size_t)(p - inc_ptr[n0])];
           uint32_t* pr = &P.pair_rec[((size_t)w * block + idx) * nen];
           if (nen == 4) {
+            P.pair_eid[(size_t)w * block + idx] = (uint32_t)e;
             uint16_t* ax = &P.pair_aux[((size_t)w * block + idx) * 8];
             const int64_t len = P.bptr[I + 1] - P.bptr[I];
             const int64_t rowoff = (int64_t)nvar * nvar * (P.bptr[I] - d.bb0);
@@ -447,7 +449,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         }
       }
     }
-    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); P.nlist.clear(); P.pair_loc.clear(); P.rg4_nl_stride = 0; }
+    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); P.nlist.clear(); P.pair_loc.clear(); P.pair_eid.clear(); P.rg4_nl_stride = 0; }
   }
   return std::string();
 }

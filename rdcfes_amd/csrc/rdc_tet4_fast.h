@@ -33,7 +33,8 @@ struct Tet4Pre {
 
 template <class M, int EXP_MODE>
 RDC_HD void tet4_prepare(const typename M::K& k, const double (&X)[4][3], const double (&U)[4][M::NV],
-                         const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Tet4Pre<M>& P) {
+                         const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Tet4Pre<M>& P,
+                         const double* ED = nullptr /* M::NELEM per-element inputs */) {
   constexpr int NV = M::NV, NG = M::NG, NA = (M::NAUX > 0 ? M::NAUX : 1);
   // ---- geometry: grad phi_1..3 = cofactors / det, grad phi_0 = -(sum) ----------------------
   double e1[3], e2[3], e3[3];
@@ -55,24 +56,27 @@ RDC_HD void tet4_prepare(const typename M::K& k, const double (&X)[4][3], const 
 #pragma unroll
   for (int j = 0; j < 4; j++) P.dd[j] = G[j][0] * G[0][0] + G[j][1] * G[0][1] + G[j][2] * G[0][2];
   // ---- constant gradient fields, projected on grad phi_0 ------------------------------------
+  double GF[NG][3];
 #pragma unroll
   for (int g = 0; g < NG; g++) {
     const int src = M::grad_src(g);
-    double gf[3];
+    if (src >= NV) { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; continue; }  // filled by grad_post()
 #pragma unroll
     for (int d = 0; d < 3; d++) {
       double s = 0.0;
 #pragma unroll
-      for (int l = 0; l < 4; l++) s += G[l][d] * (src >= 0 ? U[l][src >= 0 ? src : 0] : AX[l][src < 0 ? (-1 - src) % NA : 0]);
-      gf[d] = s;
+      for (int l = 0; l < 4; l++) s += G[l][d] * (src >= 0 ? U[l][(src >= 0 && src < NV) ? src : 0] : AX[l][src < 0 ? (-1 - src) % NA : 0]);
+      GF[g][d] = s;
     }
     if (src < 0) {  // unit radiotherapy gradient, src/ripf.C:481-484
-      const double l2 = sqrt(gf[0] * gf[0] + gf[1] * gf[1] + gf[2] * gf[2]);
-      if (l2 != 0.0) { const double il = rcp(l2); gf[0] *= il; gf[1] *= il; gf[2] *= il; }
-      else { gf[0] = 0.0; gf[1] = 0.0; gf[2] = 0.0; }
+      const double l2 = sqrt(GF[g][0] * GF[g][0] + GF[g][1] * GF[g][1] + GF[g][2] * GF[g][2]);
+      if (l2 != 0.0) { const double il = rcp(l2); GF[g][0] *= il; GF[g][1] *= il; GF[g][2] *= il; }
+      else { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; }
     }
-    P.gk[g] = gf[0] * G[0][0] + gf[1] * G[0][1] + gf[2] * G[0][2];
   }
+  if (M::NELEM > 0) M::grad_post(k, GF, ED);
+#pragma unroll
+  for (int g = 0; g < NG; g++) P.gk[g] = GF[g][0] * G[0][0] + GF[g][1] * G[0][1] + GF[g][2] * G[0][2];
   // ---- point nonlinearities at c, h_0..h_3 (point index q: 0 = c, 1 + k = h_k) ---------------
   double S[NV], SA[NA];
 #pragma unroll
@@ -151,9 +155,9 @@ RDC_HD void tet4_row(const typename M::K& k, const Tet4Pre<M>& P, int a, Sink& s
 // all rows of the pair
 template <class M, int EXP_MODE, class Sink>
 RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const double (&U)[4][M::NV],
-                      const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Sink& sink) {
+                      const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Sink& sink, const double* ED = nullptr) {
   Tet4Pre<M> P;
-  tet4_prepare<M, EXP_MODE>(k, X, U, AX, P);
+  tet4_prepare<M, EXP_MODE>(k, X, U, AX, P, ED);
 #pragma unroll
   for (int a = 0; a < M::NV; a++) tet4_row<M>(k, P, a, sink);
 }

@@ -266,7 +266,8 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
            const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
            const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
-           long long* __restrict__ stamps, const int pf_dist, const int xcd_remap) {
+           long long* __restrict__ stamps, const int pf_dist, const int xcd_remap,
+           const uint32_t* __restrict__ pair_eid, const double* __restrict__ elem) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
@@ -349,7 +350,9 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
     sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
     sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
-    tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
+    const double* ED = nullptr;  // per-element inputs (ADPM tract vector): one more 4-byte list entry per pair
+    if (M::NELEM > 0) ED = elem + (size_t)pair_eid[(size_t)w * BLOCK + idx] * M::NELEM;
+    tet4_row0<M, EXP_MODE>(k, X, U, AX, sink, ED);
     if (ABL == 2 && sink.sink == 1.2345e300) rhs[0] = sink.sink;  // keeps the arithmetic alive
   }
   if (STAMP) ts[2] = __builtin_amdgcn_s_memtime();
@@ -632,7 +635,7 @@ struct RmwSink {
 template <class M, int EXP_MODE>
 __global__ void __launch_bounds__(256)
 k_tet4_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count, const double* __restrict__ rec,
-                double* __restrict__ val, double* __restrict__ rhs) {
+                const double* __restrict__ elem, double* __restrict__ val, double* __restrict__ rhs) {
   constexpr int NV = M::NV;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
@@ -658,7 +661,7 @@ k_tet4_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t c
     sink.row = val + NV * NV * b0;
     sink.prhs = rhs + I * NV;
     sink.first_rhs = (fr >> i) & 1u;
-    tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
+    tet4_row0<M, EXP_MODE>(k, X, U, AX, sink, M::NELEM > 0 ? elem + e * M::NELEM : nullptr);
   }
 }
 
@@ -674,6 +677,8 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
+  // models with per-element inputs (M::NELEM > 0) exist only as k_tet4_rg5 and k_tet4_coloured
+  if constexpr (M::NELEM == 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
       a.opt_kernel == 4) {
     constexpr int BLOCK = 256;
@@ -691,7 +696,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     return hipGetLastError();
   }
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
-      a.opt_kernel == 0) {
+      (a.opt_kernel == 0 || M::NELEM > 0)) {
     constexpr int BLOCK = 256;
     const int nl = a.rg2.nl_stride;
     const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
@@ -699,18 +704,18 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #define RDC_RG5(MINW, ST)                                                                                          \
   hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,     \
                      a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
-                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd)
+                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem)
     if constexpr (std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) {
       // diagnostic builds (timing only, results are wrong): LDS atomics replaced by plain stores / removed
       if (a.opt_ablate == 1 || a.opt_ablate == 2) {
         if (a.opt_ablate == 1)
           hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 1>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,
                              a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs,
-                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd);
+                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem);
         else
           hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 2>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,
                              a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs,
-                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd);
+                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem);
         return hipGetLastError();
       }
     }
@@ -720,6 +725,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG5
     return hipGetLastError();
   }
+  if constexpr (M::NELEM == 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && (a.opt_kernel == 0 || a.opt_kernel == 3)) {
 #define RDC_RG3(BLOCK, MINW)                                                                                       \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
@@ -742,6 +748,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG3
     return hipGetLastError();
   }
+  if constexpr (M::NELEM == 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.opt_kernel == 2 && a.rg2.block == 256) {
     constexpr int BLOCK = 256;
 #define RDC_RG2(MINW)                                                                                              \
@@ -753,6 +760,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG2
     return hipGetLastError();
   }
+  if constexpr (M::NELEM == 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER) {
     constexpr int BLOCK = 256;
     if (a.n_wg > 0) {
@@ -785,7 +793,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     if (count <= 0) continue;
     const int64_t grid = (count + 255) / 256;
     hipLaunchKernelGGL((k_tet4_coloured<M, EXP_MODE>), dim3((unsigned)grid), dim3(256), 0, a.stream, a.m, k, first, count,
-                       a.packed, a.val, a.rhs);
+                       a.packed, a.elem, a.val, a.rhs);
   }
   return hipGetLastError();
 }
@@ -800,5 +808,6 @@ template hipError_t launch_tet4_fast<Pihna>(const LaunchArgs&, const Pihna::K&);
 template hipError_t launch_tet4_fast<PihnaNoCellTransport>(const LaunchArgs&, const PihnaNoCellTransport::K&);
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
+template hipError_t launch_tet4_fast<Adpm>(const LaunchArgs&, const Adpm::K&);
 
 }  // namespace rdc

@@ -46,7 +46,7 @@ struct ArraySinkAdapter {
 
 template <class M, int EM>
 void row_fast(const typename M::K& k, const double* Xp, const double* Up, const double* Ap, int irow, double* acc,
-              double* fe) {
+              double* fe, const double* ED = nullptr) {
   constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
   double X[4][3], U[4][NV], AX[4][NA];
   for (int j = 0; j < 4; j++) {  // rotate the row node to local 0: j -> j ^ irow (rdc_tet4_fast.h)
@@ -56,7 +56,7 @@ void row_fast(const typename M::K& k, const double* Xp, const double* Up, const 
     for (int v = 0; v < NA; v++) AX[j][v] = (M::NAUX > 0 && Ap) ? Ap[M::NAUX * jo + v] : 0.0;
   }
   ArraySinkAdapter<M> sink{{acc, fe, irow}};
-  tet4_row0<M, EM>(k, X, U, AX, sink);
+  tet4_row0<M, EM>(k, X, U, AX, sink, ED);
 }
 
 template <class M, class P>
@@ -67,12 +67,9 @@ int run(const P* p, int nen, int fast, int force_general_pow, const double* X, c
   constexpr int FE = M::FAST_EXP_MODE;
   const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == FE;
   if (fast) {
-    if constexpr (M::NELEM > 0) return 4;  // the factored TET4 row carries no per-element inputs
-    else {
-      if (nen != 4) return 1;
-      if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe); else row_fast<M, 0>(k, X, U, A, irow, acc, fe);
-      return 0;
-    }
+    if (nen != 4) return 1;
+    if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe, ED); else row_fast<M, 0>(k, X, U, A, irow, acc, fe, ED);
+    return 0;
   }
   if (nen == 4) {
     if (cube) row_generic<M, 4, FE>(k, X, U, A, irow, acc, fe, ED); else row_generic<M, 4, 0>(k, X, U, A, irow, acc, fe, ED);

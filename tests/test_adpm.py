@@ -74,10 +74,11 @@ def test_product_rows_match_oracle(oracle, shim, nen, variant):
     for seed in range(6):
         X, u, t, p = _elem(nen, 30 + seed, variant)
         Ke0, Fe0 = oracle.element(oracle.MODEL_ADPM, nen, X, u, p, elem_data=t)
-        Ke1, Fe1 = shim_rows(shim, 4, nen, p, X, u, elem_data=t)
         s = np.abs(Ke0).max()
-        np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-13 * s)
-        np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-13 * np.abs(Fe0).max())
+        for fast in ((False, True) if nen == 4 else (False,)):   # generic quadrature-loop row / factored TET4 row
+            Ke1, Fe1 = shim_rows(shim, 4, nen, p, X, u, elem_data=t, fast=fast)
+            np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-13 * s)
+            np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-13 * np.abs(Fe0).max())
 
 
 def test_tract_selection(oracle):
@@ -98,13 +99,15 @@ def test_tract_selection(oracle):
 @pytest.mark.parametrize("nen,n", [(4, 5), (8, 4)])
 @pytest.mark.parametrize("variant", ["shipped", "full"])
 @pytest.mark.parametrize("scatter", [1, 2])
-def test_gpu_parity(oracle, nen, n, variant, scatter):
+@pytest.mark.parametrize("kernel_variant", [0, 1])   # 0 = auto (factored TET4 kernels), 1 = generic evaluator
+def test_gpu_parity(oracle, nen, n, variant, scatter, kernel_variant):
     from rdcfes_amd import AssemblyContext, FIELD_ELEM_TRACTS, FIELD_OLD_SOLUTION
     conn, xyz = synth.kuhn_tet_mesh(n, jitter=0.1, order="random") if nen == 4 else synth.hex_mesh(n, jitter=0.1, order="random")
     u, tracts = synth.adpm_fields(xyz, conn.shape[0])
     p = adpm_params_from_dict(synth.adpm_param_dict(variant), time=3.0)
     _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_ADPM, nen, conn, xyz, 3, p, u_old=u, elem_fibre=tracts)
     with AssemblyContext(0) as ctx:
+        ctx.set_kernel_variant(kernel_variant)
         ctx.mesh_upload(nen, conn, xyz, 3)
         ctx.field_upload(FIELD_OLD_SOLUTION, u)
         with pytest.raises(Exception):
