@@ -147,6 +147,20 @@ typedef struct rdc_adpm_params {
   double taxis_Tau_angle;           /* "taxis/Tau/angle" in radians                            */
 } rdc_adpm_params;
 
+/* es.parameters of assemble_proteas_model, src/proteas.C:376-409 (all defaults 1.0, time_step 1e-9; :135,180-212) */
+typedef struct rdc_proteas_params {
+  double time_step;            /* "time_step"                */
+  double cells_total_capacity; /* "cells/total_capacity"     */
+  double RT_max_dosage;        /* "radiotherapy/max_dosage"  */
+  double host_proliferation, host_vsc_threshold, host_RT_death_rate, host_RT_exp_a, host_RT_exp_b, host_necrosis_rate;
+  double tumour_diffusion, tumour_diffusion_host, tumour_proliferation, tumour_vsc_threshold, tumour_RT_death_rate,
+         tumour_RT_exp_a, tumour_RT_exp_b, tumour_necrosis_rate;
+  double necrosis_clearance, necrosis_slope, necrosis_vsc_threshold;
+  double vascular_proliferation, vascular_necrosis_rate;
+  double oedema_diffusion, oedema_proliferation, oedema_vsc_threshold, oedema_RT_coeff, oedema_RT_exp,
+         oedema_reabsorption_rate;
+} rdc_proteas_params;
+
 typedef struct rdc_solid_material {
   double Young, Poisson, FibreStiffness;
   double rate[3];                      /* VolumetricStretchRatio/rate_0..2 */
@@ -216,6 +230,11 @@ int rdc_assemble_ripf(rdc_ctx* ctx, const rdc_ripf_params* p);
 int rdc_assemble_hcc(rdc_ctx* ctx, const rdc_hcc_params* p);
 /* assemble_adpm, src/adpm.C:324-652: unknowns PrP, A_b, Tau; needs RDC_FIELD_ELEM_TRACTS */
 int rdc_assemble_adpm(rdc_ctx* ctx, const rdc_adpm_params* p);
+/* assemble_proteas_model, src/proteas.C:338-705: unknowns host, tumour, necrotic, vascular,
+ * oedema; RDC_FIELD_AUX_NODAL = {AUX "HU", AUX "RTD", 0} per node.  As upstream, the radiotherapy dose at a point is
+ * phi_1 * (AUX variable 0 at LOCAL NODE 1 of the element) (src/proteas.C:481): only component 0 is read, and only
+ * at that node of every element. */
+int rdc_assemble_proteas(rdc_ctx* ctx, const rdc_proteas_params* p);
 /* residual (+ Jacobian if request_jacobian) of the SolidSystem; nvar must be 3 */
 int rdc_solid_assemble(rdc_ctx* ctx, const rdc_solid_params* p, int request_jacobian);
 

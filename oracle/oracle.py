@@ -13,7 +13,7 @@ from rdcfes_amd.params import HccParams, PihnaParams, RipfParams, SolidMaterial,
 
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "librdc_oracle.so"
-MODEL_PIHNA, MODEL_RIPF, MODEL_HCC, MODEL_SOLID, MODEL_ADPM = 0, 1, 2, 3, 4
+MODEL_PIHNA, MODEL_RIPF, MODEL_HCC, MODEL_SOLID, MODEL_ADPM, MODEL_PROTEAS = 0, 1, 2, 3, 4, 5
 _lib = None
 
 
@@ -55,7 +55,7 @@ def fe_reinit(elem_type, X):
 def element(model, elem_type, X, u, params, aux=None, elem_data=None):
     """Ke [nv*nen][nv*nen] (var-major), Fe for one element of an RD model (elem_data: ADPM tract vector)."""
     phi, dphi, jxw = fe_reinit(elem_type, X)
-    nv = {MODEL_PIHNA: 5, MODEL_RIPF: 3, MODEL_HCC: 3, MODEL_ADPM: 3}[model]
+    nv = {MODEL_PIHNA: 5, MODEL_RIPF: 3, MODEL_HCC: 3, MODEL_ADPM: 3, MODEL_PROTEAS: 5}[model]
     nd = nv * elem_type
     Ke, Fe = np.empty((nd, nd)), np.empty(nd)
     u = np.ascontiguousarray(u, dtype=np.float64)
@@ -65,6 +65,9 @@ def element(model, elem_type, X, u, params, aux=None, elem_data=None):
     elif model == MODEL_RIPF:
         aux = np.ascontiguousarray(aux, dtype=np.float64)
         L.oracle_ripf_element(elem_type, q, _p(phi), _p(dphi), _p(jxw), _p(u), _p(aux), C.byref(params), _p(Ke), _p(Fe))
+    elif model == MODEL_PROTEAS:
+        a0 = np.ascontiguousarray(np.asarray(aux, dtype=np.float64).reshape(elem_type, -1)[:, 0])
+        L.oracle_proteas_element(elem_type, q, _p(phi), _p(dphi), _p(jxw), _p(u), _p(a0), C.byref(params), _p(Ke), _p(Fe))
     elif model == MODEL_ADPM:
         ed = np.ascontiguousarray(elem_data, dtype=np.float64)
         L.oracle_adpm_element(elem_type, q, _p(phi), _p(dphi), _p(jxw), _p(u), _p(ed), C.byref(params), _p(Ke), _p(Fe))

@@ -776,6 +776,118 @@ void oracle_adpm_element(int nen, int nqp, const double* phi, const double* dphi
 #undef KE
 #undef FE
 
+/* ------------------------------------------------------------------------------------------
+ * PROTEAS                                                           src/proteas.C:338-705
+ * u: [nen][5] = (hos, tum, nec, vsc, oed); aux0: [nen] nodal values of AUX variable 0 ("HU").
+ * As upstream, RTD at a point is phi_AUX[1][qp] * AUX(dof_indices_AUX_var[0][1]) = phi_1 * aux0[1]   (:481);
+ * HU, GRAD_HU, GRAD_RTD are computed upstream but never used in the integrands.
+ * ------------------------------------------------------------------------------------------ */
+static double heaviside_(double x) { return (x > 0 ? 1 : 0); } /* src/utils.h:84 */
+#define KE(a, b) Ke[((a) * nen + i) * nd + (b) * nen + j]
+#define FE(a) Fe[(a) * nen + i]
+void oracle_proteas_element(int nen, int nqp, const double* phi, const double* dphi, const double* JxW,
+                            const double* u, const double* aux0, const rdc_proteas_params* P, double* Ke,
+                            double* Fe) {
+  const int nd = 5 * nen;
+  memset(Ke, 0, sizeof(double) * nd * nd);
+  memset(Fe, 0, sizeof(double) * nd);
+  const double DT_2 = P->time_step / 2.0, T_max = P->cells_total_capacity, RT_max = P->RT_max_dosage;
+  const double rho_h = P->host_proliferation, u_h = P->host_vsc_threshold, delta_h = P->host_RT_death_rate,
+               a_RT_h = P->host_RT_exp_a, b_RT_h = P->host_RT_exp_b, nu_h = P->host_necrosis_rate;
+  const double D_c = P->tumour_diffusion, D_c_h = P->tumour_diffusion_host, rho_c = P->tumour_proliferation,
+               u_c = P->tumour_vsc_threshold, delta_c = P->tumour_RT_death_rate, a_RT_c = P->tumour_RT_exp_a,
+               b_RT_c = P->tumour_RT_exp_b, nu_c = P->tumour_necrosis_rate;
+  const double psi_n = P->necrosis_clearance, k_n = P->necrosis_slope, u_n = P->necrosis_vsc_threshold;
+  const double rho_v = P->vascular_proliferation, nu_v = P->vascular_necrosis_rate;
+  const double D_e = P->oedema_diffusion, rho_e = P->oedema_proliferation, u_e = P->oedema_vsc_threshold,
+               xi_e = P->oedema_RT_coeff, p_RT_e = P->oedema_RT_exp, psi_e = P->oedema_reabsorption_rate;
+  for (int q = 0; q < nqp; q++) {
+    double hos_old = 0, tum_old = 0, nec_old = 0, vsc_old = 0, oed_old = 0;
+    double Gh[3] = {0, 0, 0}, Gt[3] = {0, 0, 0}, Go[3] = {0, 0, 0};
+    for (int l = 0; l < nen; l++) { /* :459-469 */
+      hos_old += PHI(l) * u[5 * l + 0];
+      tum_old += PHI(l) * u[5 * l + 1];
+      nec_old += PHI(l) * u[5 * l + 2];
+      vsc_old += PHI(l) * u[5 * l + 3];
+      oed_old += PHI(l) * u[5 * l + 4];
+      for (int d = 0; d < 3; d++) {
+        Gh[d] += DPHI(l, d) * u[5 * l + 0];
+        Gt[d] += DPHI(l, d) * u[5 * l + 1];
+        Go[d] += DPHI(l, d) * u[5 * l + 4];
+      }
+    }
+    const double RTD = PHI(1) * aux0[1]; /* :481 */
+    const double T = hos_old + tum_old + nec_old + vsc_old;
+    double Kappa = 1.0 - T / T_max;
+    Kappa = fmin(fmax(Kappa, 0.0), 1.0); /* :492 */
+    const double dKappa = -1.0 / T_max;
+    const double host_prol = rho_h * Kappa * heaviside_(vsc_old - u_h);
+    const double dhost_prol = rho_h * dKappa * heaviside_(vsc_old - u_h);
+    const double host_RT_death = delta_h * (1.0 - exp(-a_RT_h * RTD - b_RT_h * (RTD * RTD)));
+    const double host_nec = nu_h * nec_old;
+    const double tumour_prol = rho_c * Kappa * heaviside_(vsc_old - u_c);
+    const double dtumour_prol = rho_c * dKappa * heaviside_(vsc_old - u_c);
+    const double tumour_RT_death = delta_c * (1.0 - exp(-a_RT_c * RTD - b_RT_c * (RTD * RTD)));
+    const double tumour_nec = nu_c * nec_old;
+    const double nec_prol = nu_h * hos_old + nu_c * tum_old + nu_v * vsc_old;
+    const double nec_clearance = psi_n * (1.0 - tanh(k_n * vsc_old - u_n));
+    const double dnec_clearance_dv = psi_n * -k_n / (cosh(k_n * vsc_old - u_n) * cosh(k_n * vsc_old - u_n));
+    const double vsc_prol = rho_v * Kappa * tum_old;
+    const double dvsc_prol = rho_v * dKappa * tum_old;
+    const double vsc_nec = nu_v * nec_old;
+    const double oed_prol = rho_e * tum_old * (1.0 - tum_old);
+    const double doed_prol_dc = rho_e * (1.0 - 2.0 * tum_old);
+    const double oed_RT = xi_e * pow(RTD / RT_max, p_RT_e);
+    const double oed_clearance = psi_e * (1.0 - heaviside_(vsc_old - u_e));
+    const double W = JxW[q];
+    for (int i = 0; i < nen; i++) {
+      const double pi = PHI(i);
+      const double gt = dot_dphi(Gt, dphi, q, nen, i), go = dot_dphi(Go, dphi, q, nen, i);
+      const double Ght[3] = {Gh[0] * tum_old, Gh[1] * tum_old, Gh[2] * tum_old}; /* (GRAD_hos_old * tum_old) * dphi */
+      const double ght = dot_dphi(Ght, dphi, q, nen, i);
+      FE(0) += W * (hos_old * pi + DT_2 * (host_prol * hos_old * (1.0 - hos_old) * pi - host_RT_death * hos_old * pi -
+                                           host_nec * hos_old * pi));                       /* :522-529 */
+      FE(1) += W * (tum_old * pi + DT_2 * (-D_c * Kappa * gt - D_c_h * Kappa * ght + tumour_prol * tum_old * pi -
+                                           tumour_RT_death * tum_old * pi - tumour_nec * tum_old * pi)); /* :531-541 */
+      FE(2) += W * (nec_old * pi + DT_2 * (nec_prol * nec_old * pi - nec_clearance * nec_old * pi)); /* :543-550 */
+      FE(3) += W * (vsc_old * pi + DT_2 * (vsc_prol * vsc_old * pi - vsc_nec * vsc_old * pi));       /* :552-559 */
+      FE(4) += W * (oed_old * pi + DT_2 * (-D_e * go + oed_prol * oed_old * pi - oed_RT * oed_old * pi -
+                                           oed_clearance * oed_old * pi));                  /* :561-570 */
+      for (int j = 0; j < nen; j++) {
+        const double pj = PHI(j), pp = pj * pi;
+        const double dd = dphi_dphi(dphi, q, nen, j, i);
+        const double ddt = (DPHI(j, 0) * tum_old) * DPHI(i, 0) + (DPHI(j, 1) * tum_old) * DPHI(i, 1) +
+                           (DPHI(j, 2) * tum_old) * DPHI(i, 2);                             /* dphi[j]*tum_old*dphi[i] */
+        const double hh = hos_old * (1.0 - hos_old);
+        KE(0, 0) += W * (pp - DT_2 * (dhost_prol * hh * pp + host_prol * (1.0 - 2.0 * hos_old) * pp - host_RT_death * pp -
+                                      host_nec * pp));                                      /* :577-585 */
+        KE(0, 1) += W * (-DT_2 * (dhost_prol * hh * pp));                                   /* :586-590 */
+        KE(0, 2) += W * (-DT_2 * (dhost_prol * hh * pp - nu_h * pj * hos_old * pi));        /* :591-596 */
+        KE(0, 3) += W * (-DT_2 * (dhost_prol * hh * pp));                                   /* :597-601 */
+        KE(1, 0) += W * (-DT_2 * (-D_c * dKappa * pj * gt - D_c_h * dKappa * pj * ght - D_c_h * Kappa * ddt +
+                                  dtumour_prol * pj * tum_old * pi));                       /* :603-610 */
+        KE(1, 1) += W * (pp - DT_2 * (-D_c * dKappa * pj * gt - D_c * Kappa * dd + dtumour_prol * pj * tum_old * pi +
+                                      tumour_prol * pp - tumour_RT_death * pp - tumour_nec * pp)); /* :611-621 */
+        KE(1, 2) += W * (-DT_2 * (-D_c * dKappa * pj * gt - D_c_h * dKappa * pj * ght + dtumour_prol * pj * tum_old * pi -
+                                  nu_c * pj * tum_old * pi));                               /* :622-629 */
+        KE(1, 3) += W * (-DT_2 * (-D_c * dKappa * pj * gt - D_c_h * dKappa * pj * ght + dtumour_prol * pj * tum_old * pi)); /* :630-636 */
+        KE(2, 0) += W * (-DT_2 * (nu_h * pj * nec_old * pi));                               /* :638-642 */
+        KE(2, 1) += W * (-DT_2 * (nu_c * pj * nec_old * pi));                               /* :643-647 */
+        KE(2, 2) += W * (pp - DT_2 * (nec_prol * pp - nec_clearance * pp));                 /* :648-654 */
+        KE(2, 3) += W * (-DT_2 * (nu_v * pj * nec_old * pi - dnec_clearance_dv * pj * nec_old * pi)); /* :655-660 */
+        KE(3, 0) += W * (-DT_2 * (dvsc_prol * pj * vsc_old * pi));                          /* :662-666 */
+        KE(3, 1) += W * (-DT_2 * (dvsc_prol * pj * vsc_old * pi));                          /* :667-671 */
+        KE(3, 2) += W * (-DT_2 * (dvsc_prol * pj * vsc_old * pi - nu_v * pj * vsc_old * pi)); /* :672-677 */
+        KE(3, 3) += W * (pp - DT_2 * (dvsc_prol * pj * vsc_old * pi + vsc_prol * pp - vsc_nec * pp)); /* :678-685 */
+        KE(4, 1) += W * (-DT_2 * (doed_prol_dc * pj * oed_old * pi));                       /* :687-691 */
+        KE(4, 4) += W * (pp - DT_2 * (-D_e * dd + oed_prol * pp - oed_RT * pp - oed_clearance * pp)); /* :692-700 */
+      }
+    }
+  }
+}
+#undef KE
+#undef FE
+
 /* Eigenvalues of a symmetric 3x3 matrix by cyclic Jacobi rotations.  Upstream calls eigen_decomposition()
  * (src/eig3.C:261-271, Householder tridiagonalisation + QL); only the eigenVALUES are consumed
  * (src/solid_system.C:519-524), and both algorithms deliver them to a few ulp of |A|. */
@@ -1017,6 +1129,11 @@ int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, in
       case 0: oracle_pihna_element(nen, nqp, phi, dphi, JxW, U, (const rdc_pihna_params*)params, Ke, Fe); break;
       case 1: oracle_ripf_element(nen, nqp, phi, dphi, JxW, U, A, (const rdc_ripf_params*)params, Ke, Fe); break;
       case 2: oracle_hcc_element(nen, nqp, phi, dphi, JxW, U, (const rdc_hcc_params*)params, Ke, Fe); break;
+      case 5: {
+        double a0[8];
+        for (int i = 0; i < nen; i++) a0[i] = A[3 * i];
+        oracle_proteas_element(nen, nqp, phi, dphi, JxW, U, a0, (const rdc_proteas_params*)params, Ke, Fe);
+      } break;
       case 4: oracle_adpm_element(nen, nqp, phi, dphi, JxW, U, elem_fibre + 3 * e, (const rdc_adpm_params*)params, Ke, Fe); break;
       case 3: {
         const rdc_solid_params* sp = (const rdc_solid_params*)params;

@@ -38,6 +38,8 @@ int oracle_assemble_solid_sides(int elem_type, int64_t n_sides, const int64_t* s
                                 const int32_t* col_idx, double* val, double* rhs);
 void oracle_adpm_element(int nen, int nqp, const double* phi, const double* dphi, const double* JxW,
                          const double* u, const double* tracts3, const rdc_adpm_params* P, double* Ke, double* Fe);
+void oracle_proteas_element(int nen, int nqp, const double* phi, const double* dphi, const double* JxW,
+                            const double* u, const double* aux0, const rdc_proteas_params* P, double* Ke, double* Fe);
 void oracle_clamp_nonnegative(double* u, int64_t n);
 int oracle_solid_post_process(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
                               const double* xyz_undeformed, const double* elem_fibre, const int32_t* elem_material,

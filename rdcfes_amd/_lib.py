@@ -46,6 +46,7 @@ SIGNATURES = {
     "rdc_csr_values_device_ptr": (C.c_int, [ctx_p, P(C.c_void_p), P(C.c_void_p)]),
     "rdc_csr_download": (C.c_int, [ctx_p, P(dbl), P(dbl)]),
     "rdc_assemble_adpm": (C.c_int, [ctx_p, C.c_void_p]),
+    "rdc_assemble_proteas": (C.c_int, [ctx_p, C.c_void_p]),
     "rdc_clamp_nonnegative": (C.c_int, [ctx_p, C.c_int]),
     "rdc_solid_post_process": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdc_ripf_check_solution": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_double)]),

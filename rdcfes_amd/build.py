@@ -27,6 +27,7 @@ SOURCES = [
     "rdc_model_ripf.hip",
     "rdc_model_hcc.hip",
     "rdc_model_adpm.hip",
+    "rdc_model_proteas.hip",
     "rdc_tet4_fast.hip",
     "rdc_solid.hip",
 ]

@@ -183,6 +183,10 @@ class AssemblyContext:
     def assemble_hcc(self, p: HccParams):
         self._ck(self._lib.rdc_assemble_hcc(self._h, C.byref(p)))
 
+    def assemble_proteas(self, p):
+        """assemble_proteas_model (src/proteas.C:338-705); FIELD_AUX_NODAL = {HU, RTD, 0} per node."""
+        self._ck(self._lib.rdc_assemble_proteas(self._h, C.byref(p)))
+
     def assemble_adpm(self, p):
         """assemble_adpm (src/adpm.C:324-652); the tract vectors go into FIELD_ELEM_TRACTS first."""
         self._ck(self._lib.rdc_assemble_adpm(self._h, C.byref(p)))

@@ -597,6 +597,7 @@ int rdc_assemble_pihna(rdc_ctx* c, const rdc_pihna_params* p) { return assemble_
 int rdc_assemble_ripf(rdc_ctx* c, const rdc_ripf_params* p) { return assemble_rd<Ripf>(c, p, 3, true); }
 int rdc_assemble_hcc(rdc_ctx* c, const rdc_hcc_params* p) { return assemble_rd<Hcc>(c, p, 3, false); }
 int rdc_assemble_adpm(rdc_ctx* c, const rdc_adpm_params* p) { return assemble_rd<Adpm>(c, p, 3, false); }
+int rdc_assemble_proteas(rdc_ctx* c, const rdc_proteas_params* p) { return assemble_rd<Proteas>(c, p, 5, true); }
 
 int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobian) {
   if (!c) return RDC_ERR_INVALID;

@@ -96,6 +96,7 @@ struct PihnaK {  // src/pihna.C:358-381
 };
 
 struct Pihna {
+  static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 0;  // per-element input doubles
   RDC_HD static void grad_post(const PihnaK&, double (*)[3], const double*) {}
   static constexpr int NV = 5, NG = 4, NAUX = 0;
@@ -276,6 +277,7 @@ struct RipfK {
 };
 
 struct Ripf {
+  static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 0;  // per-element input doubles
   RDC_HD static void grad_post(const RipfK&, double (*)[3], const double*) {}
   static constexpr int NV = 3, NG = 3, NAUX = 3;
@@ -410,6 +412,7 @@ struct HccK {
 };
 
 struct Hcc {
+  static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 0;  // per-element input doubles
   RDC_HD static void grad_post(const HccK&, double (*)[3], const double*) {}
   static constexpr int NV = 3, NG = 1, NAUX = 0;
@@ -530,6 +533,7 @@ struct AdpmK {
 };
 
 struct Adpm {
+  static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 3;   // tract vector of the element
   static constexpr int NV = 3, NG = 4, NAUX = 0;
   static constexpr int FAST_EXP_MODE = 1;  // no power law in this model
@@ -634,6 +638,133 @@ struct Adpm {
     o.D[2][2] = T * s.difT;
     o.B[2][2][3] = T * s.t1T;
     o.B[2][2][2] = -T * s.t2T;
+  }
+};
+
+// =========================================================================================
+// PROTEAS (src/proteas.C:338-705): unknowns (hos, tum, nec, vsc, oed); gradient fields 0 = grad tum,
+// 1 = grad hos, 2 = grad oed.  Quirks kept: the dose RTD at a point is phi_1 * (AUX variable 0 at local node 1)
+// (:481: index [0][1] of the AUX dof table) -- expressed here as the interpolation of an aux nodal field that is
+// masked to local node 1 (AUX_LOCAL_NODE); dKappa = -1/T_max also where Kappa is clamped (:494); the
+// d(vsc_prol)/d(tum) column omits rho_v*Kappa*vsc (:661-670).
+// =========================================================================================
+struct ProteasK {
+  double DT2, T_max, i_RT_max;
+  double rho_h, u_h, delta_h, a_RT_h, b_RT_h, nu_h;
+  double D_c, D_c_h, rho_c, u_c, delta_c, a_RT_c, b_RT_c, nu_c;
+  double psi_n, k_n, u_n, rho_v, nu_v;
+  double D_e, rho_e, u_e, xi_e, p_RT_e, psi_e;
+};
+
+struct Proteas {
+  static constexpr int AUX_LOCAL_NODE = 1;
+  static constexpr int NELEM = 0;
+  RDC_HD static void grad_post(const ProteasK&, double (*)[3], const double*) {}
+  static constexpr int NV = 5, NG = 3, NAUX = 3;
+  static constexpr int FAST_EXP_MODE = 1;  // oedema/RT_exp = 1 (the default): (RTD/RT_max)^1
+  using K = ProteasK;
+  using C = Coef<NV, NG>;
+  RDC_HD static constexpr int grad_src(int k) { return k == 0 ? 1 : (k == 1 ? 0 : 4); }
+  RDC_HD static constexpr int row_order(int x) { return x; }
+  RDC_HD static constexpr bool hasA(int a, int b) { return a < 4 ? b < 4 : (b == 1 || b == 4); }
+  RDC_HD static constexpr bool hasB(int a, int b, int k) { return a == 1 && b < 4 && (k == 0 || (k == 1 && b != 1)); }
+  RDC_HD static constexpr bool hasD(int a, int b) { return (a == 1 && b <= 1) || (a == 4 && b == 4); }
+  RDC_HD static constexpr bool hasRG(int a, int k) { return (a == 1 && k <= 1) || (a == 4 && k == 2); }
+
+  static inline K derive(const rdc_proteas_params& p) {
+    K k;
+    k.DT2 = p.time_step / 2.0;
+    k.T_max = p.cells_total_capacity; k.i_RT_max = 1.0 / p.RT_max_dosage;
+    k.rho_h = p.host_proliferation; k.u_h = p.host_vsc_threshold; k.delta_h = p.host_RT_death_rate;
+    k.a_RT_h = p.host_RT_exp_a; k.b_RT_h = p.host_RT_exp_b; k.nu_h = p.host_necrosis_rate;
+    k.D_c = p.tumour_diffusion; k.D_c_h = p.tumour_diffusion_host; k.rho_c = p.tumour_proliferation;
+    k.u_c = p.tumour_vsc_threshold; k.delta_c = p.tumour_RT_death_rate; k.a_RT_c = p.tumour_RT_exp_a;
+    k.b_RT_c = p.tumour_RT_exp_b; k.nu_c = p.tumour_necrosis_rate;
+    k.psi_n = p.necrosis_clearance; k.k_n = p.necrosis_slope; k.u_n = p.necrosis_vsc_threshold;
+    k.rho_v = p.vascular_proliferation; k.nu_v = p.vascular_necrosis_rate;
+    k.D_e = p.oedema_diffusion; k.rho_e = p.oedema_proliferation; k.u_e = p.oedema_vsc_threshold;
+    k.xi_e = p.oedema_RT_coeff; k.p_RT_e = p.oedema_RT_exp; k.psi_e = p.oedema_reabsorption_rate;
+    return k;
+  }
+  static inline double exponent(const K& k) { return k.p_RT_e; }
+
+  struct Pt {
+    double hos, tum, nec, vsc, oed;
+    double Kap, hp, dhp, hRT, tp, dtp, tRT, nclr, dnclr, dvp, oRT, oclr;
+  };
+
+  template <int EXP_MODE>
+  RDC_HD static void point(const K& k, const double* u, const double* aux, Pt& s) {
+    s.hos = u[0]; s.tum = u[1]; s.nec = u[2]; s.vsc = u[3]; s.oed = u[4];
+    const double RTD = aux[0];                                               // masked interpolation, see above
+    const double Tt = s.hos + s.tum + s.nec + s.vsc;                         // :490
+    double Kap = 1.0 - Tt / k.T_max;                                         // :491-492
+    Kap = (Kap > 0.0 ? Kap : 0.0);
+    Kap = (Kap < 1.0 ? Kap : 1.0);
+    s.Kap = Kap;
+    const double dK = -1.0 / k.T_max;                                        // :493
+    const double Hh = (s.vsc - k.u_h > 0.0 ? 1.0 : 0.0), Hc = (s.vsc - k.u_c > 0.0 ? 1.0 : 0.0);
+    s.hp = k.rho_h * Kap * Hh; s.dhp = k.rho_h * dK * Hh;                    // :495-496
+    s.hRT = k.delta_h * (1.0 - exp(-k.a_RT_h * RTD - k.b_RT_h * (RTD * RTD)));  // :497
+    s.tp = k.rho_c * Kap * Hc; s.dtp = k.rho_c * dK * Hc;                    // :500-501
+    s.tRT = k.delta_c * (1.0 - exp(-k.a_RT_c * RTD - k.b_RT_c * (RTD * RTD)));  // :502
+    const double arg = k.k_n * s.vsc - k.u_n;
+    s.nclr = k.psi_n * (1.0 - tanh(arg));                                    // :506
+    const double ch = cosh(arg);
+    s.dnclr = k.psi_n * -k.k_n / (ch * ch);                                  // :507
+    s.dvp = k.rho_v * dK * s.tum;                                            // :510
+    const double x = RTD * k.i_RT_max;
+    s.oRT = k.xi_e * (EXP_MODE == 1 ? x : pow(x, k.p_RT_e));                 // :515
+    s.oclr = k.psi_e * (1.0 - (s.vsc - k.u_e > 0.0 ? 1.0 : 0.0));            // :516
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
+    o.zero();
+    const double T = k.DT2, dK = -1.0 / k.T_max;
+    const double hn = k.nu_h * s.nec, tn = k.nu_c * s.nec;                   // :498,503
+    const double np_ = k.nu_h * s.hos + k.nu_c * s.tum + k.nu_v * s.vsc;     // :505
+    const double vp = k.rho_v * s.Kap * s.tum, vn = k.nu_v * s.nec;          // :509,511
+    const double op = k.rho_e * s.tum * (1.0 - s.tum), dop = k.rho_e * (1.0 - 2.0 * s.tum);  // :513-514
+    const double hh = s.hos * (1.0 - s.hos);
+    // host, :522-529 and :575-601
+    o.R[0] = s.hos + T * (s.hp * hh - s.hRT * s.hos - hn * s.hos);
+    o.A[0][0] = 1.0 - T * (s.dhp * hh + s.hp * (1.0 - 2.0 * s.hos) - s.hRT - hn);
+    o.A[0][1] = -T * (s.dhp * hh);
+    o.A[0][2] = -T * (s.dhp * hh - k.nu_h * s.hos);
+    o.A[0][3] = -T * (s.dhp * hh);
+    // tumour, :531-541 and :603-640
+    o.R[1] = s.tum + T * (s.tp * s.tum - s.tRT * s.tum - tn * s.tum);
+    o.RG[1][0] = -T * k.D_c * s.Kap;
+    o.RG[1][1] = -T * k.D_c_h * s.Kap * s.tum;
+    const double bt = T * k.D_c * dK, bh = T * k.D_c_h * dK * s.tum;
+    o.A[1][0] = -T * (s.dtp * s.tum);
+    o.B[1][0][0] = bt; o.B[1][0][1] = bh;
+    o.D[1][0] = T * k.D_c_h * s.Kap * s.tum;
+    o.A[1][1] = 1.0 - T * (s.dtp * s.tum + s.tp - s.tRT - tn);
+    o.B[1][1][0] = bt;
+    o.D[1][1] = T * k.D_c * s.Kap;
+    o.A[1][2] = -T * (s.dtp * s.tum - k.nu_c * s.tum);
+    o.B[1][2][0] = bt; o.B[1][2][1] = bh;
+    o.A[1][3] = -T * (s.dtp * s.tum);
+    o.B[1][3][0] = bt; o.B[1][3][1] = bh;
+    // necrotic, :543-550 and :642-665
+    o.R[2] = s.nec + T * (np_ * s.nec - s.nclr * s.nec);
+    o.A[2][0] = -T * (k.nu_h * s.nec);
+    o.A[2][1] = -T * (k.nu_c * s.nec);
+    o.A[2][2] = 1.0 - T * (np_ - s.nclr);
+    o.A[2][3] = -T * (k.nu_v * s.nec - s.dnclr * s.nec);
+    // vascular, :552-559 and :667-692
+    o.R[3] = s.vsc + T * (vp * s.vsc - vn * s.vsc);
+    o.A[3][0] = -T * (s.dvp * s.vsc);
+    o.A[3][1] = -T * (s.dvp * s.vsc);
+    o.A[3][2] = -T * (s.dvp * s.vsc - k.nu_v * s.vsc);
+    o.A[3][3] = 1.0 - T * (s.dvp * s.vsc + vp - vn);
+    // oedema, :561-570 and :694-709
+    o.R[4] = s.oed + T * (op * s.oed - s.oRT * s.oed - s.oclr * s.oed);
+    o.RG[4][2] = -T * k.D_e;
+    o.A[4][1] = -T * (dop * s.oed);
+    o.A[4][4] = 1.0 - T * (op - s.oRT - s.oclr);
+    o.D[4][4] = T * k.D_e;
   }
 };
 

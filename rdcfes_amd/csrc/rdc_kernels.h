@@ -49,7 +49,8 @@ __device__ __forceinline__ void load_element(const MeshDev& m, int64_t e, const 
     for (int v = 0; v < M::NV; v++) U[i][v] = u[n * M::NV + v];
     if (M::NAUX > 0) {
 #pragma unroll
-      for (int v = 0; v < M::NAUX; v++) AX[i][v] = aux[n * M::NAUX + v];
+      for (int v = 0; v < M::NAUX; v++)  // PROTEAS reads its aux field at one local node only (AUX_LOCAL_NODE)
+        AX[i][v] = (M::AUX_LOCAL_NODE < 0 || i == M::AUX_LOCAL_NODE) ? aux[n * M::NAUX + v] : 0.0;
     } else {
       AX[i][0] = 0.0;
     }

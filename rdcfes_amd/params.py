@@ -49,6 +49,20 @@ class AdpmParams(C.Structure):
                 ("taxis_A_b_angle", _D), ("taxis_Tau_angle", _D)]
 
 
+_PROTEAS_FIELDS = ["time_step", "cells_total_capacity", "RT_max_dosage", "host_proliferation", "host_vsc_threshold",
+                   "host_RT_death_rate", "host_RT_exp_a", "host_RT_exp_b", "host_necrosis_rate", "tumour_diffusion",
+                   "tumour_diffusion_host", "tumour_proliferation", "tumour_vsc_threshold", "tumour_RT_death_rate",
+                   "tumour_RT_exp_a", "tumour_RT_exp_b", "tumour_necrosis_rate", "necrosis_clearance", "necrosis_slope",
+                   "necrosis_vsc_threshold", "vascular_proliferation", "vascular_necrosis_rate", "oedema_diffusion",
+                   "oedema_proliferation", "oedema_vsc_threshold", "oedema_RT_coeff", "oedema_RT_exp",
+                   "oedema_reabsorption_rate"]
+
+
+class ProteasParams(C.Structure):
+    """rdc_proteas_params, src/proteas.C:376-409."""
+    _fields_ = [(f, _D) for f in _PROTEAS_FIELDS]
+
+
 class RipfCheckParams(C.Structure):
     """rdc_ripf_check_params: what check_solution reads, src/ripf.C:697-703."""
     _fields_ = [("time_step", _D), ("HU_min", _D), ("HU_max", _D), ("RT_broad_fractions", C.c_int32),
@@ -172,4 +186,24 @@ def adpm_params_from_dict(d, time=0.0):
             setattr(p, field, v)
         else:
             getattr(p, field)[idx] = v
+    return p
+
+
+# PROTEAS: reference key -> struct field; defaults of input(), src/proteas.C:135,180-212
+PROTEAS_KEYS = {"time_step": "time_step", "cells/total_capacity": "cells_total_capacity",
+                "radiotherapy/max_dosage": "RT_max_dosage"}
+for _f in _PROTEAS_FIELDS[3:]:
+    _grp, _rest = _f.split("_", 1)
+    PROTEAS_KEYS[f"{_grp}/{_rest}"] = _f
+PROTEAS_DEFAULTS = {k: 1.0 for k in PROTEAS_KEYS}
+PROTEAS_DEFAULTS["time_step"] = 1.0e-9
+
+
+def proteas_params_from_dict(d):
+    unknown = set(d) - set(PROTEAS_KEYS)
+    if unknown:
+        raise KeyError(f"unknown PROTEAS parameter keys: {sorted(unknown)}")
+    p = ProteasParams()
+    for key, field in PROTEAS_KEYS.items():
+        setattr(p, field, float(d.get(key, PROTEAS_DEFAULTS[key])))
     return p

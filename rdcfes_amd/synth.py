@@ -167,9 +167,44 @@ def adpm_param_dict(variant="shipped"):
     return d
 
 
+def proteas_param_dict(variant="full"):
+    """No PROTEAS example ships with the reference; 'defaults' = input()'s all-ones (src/proteas.C:180-212),
+    'full' = distinct values with the thresholds inside the range of proteas_fields() and a real RT exponent."""
+    if variant == "defaults":
+        return {"time_step": 0.05}
+    if variant != "full":
+        raise ValueError(variant)
+    return {"time_step": 0.05, "cells/total_capacity": 1.6, "radiotherapy/max_dosage": 60.0,
+            "host/proliferation": 0.3, "host/vsc_threshold": 0.05, "host/RT_death_rate": 0.2, "host/RT_exp_a": 0.03,
+            "host/RT_exp_b": 0.002, "host/necrosis_rate": 0.15, "tumour/diffusion": 0.02, "tumour/diffusion_host": 0.01,
+            "tumour/proliferation": 0.8, "tumour/vsc_threshold": 0.08, "tumour/RT_death_rate": 0.5, "tumour/RT_exp_a": 0.05,
+            "tumour/RT_exp_b": 0.004, "tumour/necrosis_rate": 0.25, "necrosis/clearance": 0.1, "necrosis/slope": 6.0,
+            "necrosis/vsc_threshold": 0.5, "vascular/proliferation": 0.4, "vascular/necrosis_rate": 0.2,
+            "oedema/diffusion": 0.05, "oedema/proliferation": 0.6, "oedema/vsc_threshold": 0.1, "oedema/RT_coeff": 0.3,
+            "oedema/RT_exp": 1.5, "oedema/reabsorption_rate": 0.35}
+
+
 # ---------------------------------------------------------------------------------------------
 # fields
 # ---------------------------------------------------------------------------------------------
+def proteas_fields(xyz, seed=SEED):
+    """([n_node][5] (hos, tum, nec, vsc, oed) volume fractions, [n_node][3] aux = {HU, RTD, 0}); the dose-like
+    aux component 0 is positive (upstream raises RTD/RT_max to a real power)."""
+    rng = np.random.default_rng(seed + 11)
+    n = xyz.shape[0]
+    r = np.linalg.norm(xyz - 0.5, axis=1)
+    u = np.empty((n, 5))
+    u[:, 0] = 0.5 + 0.2 * np.cos(3.0 * xyz[:, 0]) + rng.uniform(-0.02, 0.02, n)
+    u[:, 1] = 0.35 * np.exp(-(r / 0.3) ** 2) + rng.uniform(0.0, 0.02, n)
+    u[:, 2] = 0.1 * np.exp(-(r / 0.15) ** 2) + rng.uniform(0.0, 0.01, n)
+    u[:, 3] = 0.12 + 0.08 * np.sin(4.0 * xyz[:, 1]) + rng.uniform(-0.01, 0.01, n)
+    u[:, 4] = 0.2 * np.exp(-(r / 0.4) ** 2) + rng.uniform(0.0, 0.02, n)
+    aux = np.zeros((n, 3))
+    aux[:, 0] = 5.0 + 40.0 * np.exp(-(r / 0.35) ** 2) + rng.uniform(0.0, 1.0, n)
+    aux[:, 1] = rng.uniform(0.0, 60.0, n)   # never read by the assembly (src/proteas.C:481 indexes variable 0)
+    return u, aux
+
+
 def adpm_fields(xyz, n_elem, seed=SEED):
     """([n_node][3] (PrP, A_b, Tau), [n_elem][3] tract vectors): PrP around the shipped background 1
     (run/HCP102513/Brain_Model_Initial_Nodal_Field.dat), misfolded species in [0, 0.02] with smooth parts so

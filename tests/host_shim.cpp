@@ -21,7 +21,8 @@ void row_generic(const typename M::K& k, const double* Xp, const double* Up, con
   for (int i = 0; i < NEN; i++) {
     for (int d = 0; d < 3; d++) X[i][d] = Xp[3 * i + d];
     for (int v = 0; v < NV; v++) U[i][v] = Up[NV * i + v];
-    for (int v = 0; v < NA; v++) AX[i][v] = (M::NAUX > 0 && Ap) ? Ap[M::NAUX * i + v] : 0.0;
+    for (int v = 0; v < NA; v++)
+      AX[i][v] = (M::NAUX > 0 && Ap && (M::AUX_LOCAL_NODE < 0 || i == M::AUX_LOCAL_NODE)) ? Ap[M::NAUX * i + v] : 0.0;
   }
   double a[NV][NV][NEN], f[NV];
   rd_row<M, NEN, EM>(k, X, U, AX, irow, a, f, ED);
@@ -67,6 +68,7 @@ int run(const P* p, int nen, int fast, int force_general_pow, const double* X, c
   constexpr int FE = M::FAST_EXP_MODE;
   const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == FE;
   if (fast) {
+    if (M::AUX_LOCAL_NODE >= 0) return 4;  // a per-local-node aux mask is only known to the generic evaluator
     if (nen != 4) return 1;
     if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe, ED); else row_fast<M, 0>(k, X, U, A, irow, acc, fe, ED);
     return 0;
@@ -113,6 +115,7 @@ extern "C" {
 int shim_row(int model, int nen, int fast, int force_general_pow, const void* params, const double* X, const double* U,
              const double* A, int irow, double* acc, double* fe, const double* ED) {
   switch (model) {
+    case 5: return run<Proteas>((const rdc_proteas_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe, ED);
     case 4: return run<Adpm>((const rdc_adpm_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe, ED);
     case 0: return run<Pihna>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
     case 1: return run<Ripf>((const rdc_ripf_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
@@ -132,6 +135,7 @@ int shim_masks(int model, const void* params, const double* u, const double* aux
     case 2: return masks<Hcc>((const rdc_hcc_params*)params, u, aux, worst);
     case 3: return masks<PihnaNoCellTransport>((const rdc_pihna_params*)params, u, aux, worst);
     case 4: return masks<Adpm>((const rdc_adpm_params*)params, u, aux, worst);
+    case 5: return masks<Proteas>((const rdc_proteas_params*)params, u, aux, worst);
   }
   return 2;
 }

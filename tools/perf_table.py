@@ -4,7 +4,7 @@ import json, sys, time
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from rdcfes_amd import (AssemblyContext, SolidMaterial, SolidParams, adpm_params_from_dict, hcc_params_from_dict, pihna_params_from_dict,
+from rdcfes_amd import (AssemblyContext, SolidMaterial, SolidParams, adpm_params_from_dict, proteas_params_from_dict, hcc_params_from_dict, pihna_params_from_dict,
                         ripf_params_from_dict, synth)
 from rdcfes_amd.context import FIELD_AUX_NODAL, FIELD_ELEM_FIBRE, FIELD_OLD_SOLUTION, FIELD_UNDEFORMED_XYZ
 
@@ -53,6 +53,15 @@ for w in which:
         conn, xyz = synth.kuhn_tet_mesh(94)
         p, u = hcc_params_from_dict(synth.hcc_param_dict("full")), synth.hcc_fields(xyz)
         run("HCC TET4 K(94)", 4, conn, xyz, 3, lambda c: c.field_upload(FIELD_OLD_SOLUTION, u), lambda c: c.assemble_hcc(p), 2)
+    elif w.startswith("proteas"):
+        hexm = w.endswith("hex")
+        n = int(w.replace("proteas", "").replace("hex", "") or 60)
+        conn, xyz = synth.hex_mesh(n, jitter=0.1) if hexm else synth.kuhn_tet_mesh(n)
+        u, aux = synth.proteas_fields(xyz)
+        p = proteas_params_from_dict(synth.proteas_param_dict("full"))
+        def setup(c):
+            c.field_upload(FIELD_OLD_SOLUTION, u); c.field_upload(FIELD_AUX_NODAL, aux)
+        run(f"PROTEAS {'HEX8 H' if hexm else 'TET4 K'}({n})", 8 if hexm else 4, conn, xyz, 5, setup, lambda c: c.assemble_proteas(p), 2, reps=3, n_in=6)
     elif w.startswith("adpm"):
         hexm = w.endswith("hex")
         n = int(w.replace("adpm", "").replace("hex", "") or 60)
