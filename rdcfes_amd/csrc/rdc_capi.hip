@@ -236,7 +236,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
       a.rg2.nlist = (const uint32_t*)c->rg4_nlist.p;
       a.rg2.pair_loc = (const uint32_t*)c->rg4_ploc.p;
       a.rg2.nl_stride = c->prep.rg4_nl_stride;
-      if (M::NELEM > 0 && !c->prep.pair_eid.empty()) {
+      if ((M::NELEM > 0 || M::AUX_LOCAL_NODE >= 0) && !c->prep.pair_eid.empty()) {
         if (!c->rg5_eid_ready) {
           if ((rc = dev_upload(c, c->rg5_eid, c->prep.pair_eid))) return rc;
           c->rg5_eid_ready = true;

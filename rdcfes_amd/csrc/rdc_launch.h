@@ -30,11 +30,10 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
 
 template <class M>
 hipError_t launch_rd(const LaunchArgs& a, const typename M::K& k) {
-  if constexpr (M::AUX_LOCAL_NODE < 0)  // a per-local-node aux mask is only known to the generic evaluator
   if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC) {
-    // per-element inputs (M::NELEM > 0) travel only in k_tet4_rg5 (needs the pair -> element list) and k_tet4_coloured
+    // per-element inputs (M::NELEM > 0) and the local-node aux mask (Proteas) travel only in k_tet4_rg5 (needs the pair -> element list) and k_tet4_coloured
     const bool rg5 = a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 && a.rg2.pair_eid;
-    if (M::NELEM == 0 || a.strategy != RDC_SCATTER_ROWGATHER || rg5) return launch_tet4_fast<M>(a, k);
+    if ((M::NELEM == 0 && M::AUX_LOCAL_NODE < 0) || a.strategy != RDC_SCATTER_ROWGATHER || rg5) return launch_tet4_fast<M>(a, k);
   }
   if (a.nen == 4) {
     if (a.exp_mode == M::FAST_EXP_MODE) return launch_rd_impl<M, 4, M::FAST_EXP_MODE>(a, k);

@@ -390,7 +390,12 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
           const std::array<int, 4>& cols = col_of[(size_t)(p - inc_ptr[n0])];
           uint32_t* pr = &P.pair_rec[((size_t)w * block + idx) * nen];
           if (nen == 4) {
-            P.pair_eid[(size_t)w * block + idx] = (uint32_t)e;
+            // element of the pair; bits 30-31: which rotated column holds the element's local node 1
+            // (models whose aux field is read at that node only, Proteas::AUX_LOCAL_NODE)
+            uint32_t pos1 = 0;
+            for (int j = 0; j < 4; j++) if (cols[j] == 1) pos1 = (uint32_t)j;
+            P.pair_eid[(size_t)w * block + idx] = (uint32_t)e | (pos1 << 30);
+            if ((uint64_t)e >= (1ull << 30)) fail_flag = 1;
             uint16_t* ax = &P.pair_aux[((size_t)w * block + idx) * 8];
             const int64_t len = P.bptr[I + 1] - P.bptr[I];
             const int64_t rowoff = (int64_t)nvar * nvar * (P.bptr[I] - d.bb0);

@@ -351,7 +351,17 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
     sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
     const double* ED = nullptr;  // per-element inputs (ADPM tract vector): one more 4-byte list entry per pair
-    if (M::NELEM > 0) ED = elem + (size_t)pair_eid[(size_t)w * BLOCK + idx] * M::NELEM;
+    if (M::NELEM > 0 || M::AUX_LOCAL_NODE >= 0) {
+      const uint32_t pe = pair_eid[(size_t)w * BLOCK + idx];
+      if (M::NELEM > 0) ED = elem + (size_t)(pe & 0x3FFFFFFFu) * M::NELEM;
+      if (M::AUX_LOCAL_NODE >= 0) {  // aux field read at local node 1 of the element only (src/proteas.C:481)
+        const int pos1 = (int)(pe >> 30);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int v = 0; v < (M::NAUX > 0 ? M::NAUX : 1); v++) AX[j][v] = (j == pos1) ? AX[j][v] : 0.0;
+      }
+    }
     tet4_row0<M, EXP_MODE>(k, X, U, AX, sink, ED);
     if (ABL == 2 && sink.sink == 1.2345e300) rhs[0] = sink.sink;  // keeps the arithmetic alive
   }
@@ -653,6 +663,10 @@ k_tet4_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t c
       const int jo = j ^ i;
       const int64_t n = m.conn[e * 4 + jo];
       load_rec<M>(rec, n, X[j], U[j], AX[j]);
+      if (M::AUX_LOCAL_NODE >= 0 && jo != M::AUX_LOCAL_NODE) {
+#pragma unroll
+        for (int v = 0; v < (M::NAUX > 0 ? M::NAUX : 1); v++) AX[j][v] = 0.0;
+      }
       sink.off[j] = NV * (int64_t)m.eslot[e * 16 + i * 4 + jo];
       sink.first[j] = (fm >> (i * 4 + jo)) & 1ull;
     }
@@ -677,8 +691,8 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
-  // models with per-element inputs (M::NELEM > 0) exist only as k_tet4_rg5 and k_tet4_coloured
-  if constexpr (M::NELEM == 0)
+  // models with per-element inputs (M::NELEM > 0) or a local-node aux mask exist only as k_tet4_rg5 and k_tet4_coloured
+  if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
       a.opt_kernel == 4) {
     constexpr int BLOCK = 256;
@@ -696,7 +710,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     return hipGetLastError();
   }
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
-      (a.opt_kernel == 0 || M::NELEM > 0)) {
+      (a.opt_kernel == 0 || M::NELEM > 0 || M::AUX_LOCAL_NODE >= 0)) {
     constexpr int BLOCK = 256;
     const int nl = a.rg2.nl_stride;
     const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
@@ -725,7 +739,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG5
     return hipGetLastError();
   }
-  if constexpr (M::NELEM == 0)
+  if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && (a.opt_kernel == 0 || a.opt_kernel == 3)) {
 #define RDC_RG3(BLOCK, MINW)                                                                                       \
   hipLaunchKernelGGL((k_tet4_rg3<M, EXP_MODE, BLOCK, MINW>), dim3(a.rg2.n_wg), dim3(BLOCK), a.rg2.lds_bytes, a.stream, \
@@ -748,7 +762,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG3
     return hipGetLastError();
   }
-  if constexpr (M::NELEM == 0)
+  if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.opt_kernel == 2 && a.rg2.block == 256) {
     constexpr int BLOCK = 256;
 #define RDC_RG2(MINW)                                                                                              \
@@ -760,7 +774,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #undef RDC_RG2
     return hipGetLastError();
   }
-  if constexpr (M::NELEM == 0)
+  if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER) {
     constexpr int BLOCK = 256;
     if (a.n_wg > 0) {
@@ -809,5 +823,6 @@ template hipError_t launch_tet4_fast<PihnaNoCellTransport>(const LaunchArgs&, co
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
 template hipError_t launch_tet4_fast<Adpm>(const LaunchArgs&, const Adpm::K&);
+template hipError_t launch_tet4_fast<Proteas>(const LaunchArgs&, const Proteas::K&);
 
 }  // namespace rdc

@@ -54,7 +54,8 @@ void row_fast(const typename M::K& k, const double* Xp, const double* Up, const 
     const int jo = j ^ irow;
     for (int d = 0; d < 3; d++) X[j][d] = Xp[3 * jo + d];
     for (int v = 0; v < NV; v++) U[j][v] = Up[NV * jo + v];
-    for (int v = 0; v < NA; v++) AX[j][v] = (M::NAUX > 0 && Ap) ? Ap[M::NAUX * jo + v] : 0.0;
+    for (int v = 0; v < NA; v++)
+      AX[j][v] = (M::NAUX > 0 && Ap && (M::AUX_LOCAL_NODE < 0 || jo == M::AUX_LOCAL_NODE)) ? Ap[M::NAUX * jo + v] : 0.0;
   }
   ArraySinkAdapter<M> sink{{acc, fe, irow}};
   tet4_row0<M, EM>(k, X, U, AX, sink, ED);
@@ -68,7 +69,6 @@ int run(const P* p, int nen, int fast, int force_general_pow, const double* X, c
   constexpr int FE = M::FAST_EXP_MODE;
   const bool cube = !force_general_pow && exp_mode_of(M::exponent(k)) == FE;
   if (fast) {
-    if (M::AUX_LOCAL_NODE >= 0) return 4;  // a per-local-node aux mask is only known to the generic evaluator
     if (nen != 4) return 1;
     if (cube) row_fast<M, FE>(k, X, U, A, irow, acc, fe, ED); else row_fast<M, 0>(k, X, U, A, irow, acc, fe, ED);
     return 0;

@@ -63,23 +63,26 @@ def test_product_rows_match_oracle(oracle, shim, nen, variant):
     for seed in range(6):
         X, u, aux, p = _elem(nen, 30 + seed, variant)
         Ke0, Fe0 = oracle.element(oracle.MODEL_PROTEAS, nen, X, u, p, aux=aux)
-        Ke1, Fe1 = shim_rows(shim, 5, nen, p, X, u, aux)
         s = np.abs(Ke0).max()
-        np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-13 * s)
-        np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-13 * np.abs(Fe0).max())
+        for fast in ((False, True) if nen == 4 else (False,)):
+            Ke1, Fe1 = shim_rows(shim, 5, nen, p, X, u, aux, fast=fast)
+            np.testing.assert_allclose(Ke1, Ke0, rtol=1e-10, atol=1e-13 * s)
+            np.testing.assert_allclose(Fe1, Fe0, rtol=1e-10, atol=1e-13 * np.abs(Fe0).max())
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nen,n", [(4, 5), (8, 4)])
 @pytest.mark.parametrize("variant", ["defaults", "full"])
 @pytest.mark.parametrize("scatter", [1, 2])
-def test_gpu_parity(oracle, nen, n, variant, scatter):
+@pytest.mark.parametrize("kernel_variant", [0, 1])   # 0 = auto (factored TET4 kernels), 1 = generic evaluator
+def test_gpu_parity(oracle, nen, n, variant, scatter, kernel_variant):
     from rdcfes_amd import AssemblyContext, FIELD_AUX_NODAL, FIELD_OLD_SOLUTION
     conn, xyz = synth.kuhn_tet_mesh(n, jitter=0.1, order="random") if nen == 4 else synth.hex_mesh(n, jitter=0.1, order="random")
     u, aux = synth.proteas_fields(xyz)
     p = proteas_params_from_dict(synth.proteas_param_dict(variant))
     _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_PROTEAS, nen, conn, xyz, 5, p, u_old=u, aux=aux)
     with AssemblyContext(0) as ctx:
+        ctx.set_kernel_variant(kernel_variant)
         ctx.mesh_upload(nen, conn, xyz, 5)
         ctx.field_upload(FIELD_OLD_SOLUTION, u)
         with pytest.raises(Exception):
