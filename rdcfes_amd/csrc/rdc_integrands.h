@@ -68,6 +68,15 @@ RDC_HD double rcp(double x) {
 #endif
 }
 
+// pow() kept out of line on the device: inlined into the generic row-gather kernel of a 5-unknown model (256 VGPRs
+// + AGPR spills) the device-library pow produced NaN for positive arguments (observed with Proteas on TET4,
+// ROCm 7.2); as a call it is correct everywhere, and the general-exponent path is the rare one.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) static double rdc_pow(double x, double e) { return pow(x, e); }
+#else
+static inline double rdc_pow(double x, double e) { return pow(x, e); }
+#endif
+
 // x^e for the crowding functions.  The reference calls pow(1-Te, ek) with a real exponent
 // (src/pihna.C:466); for the small integer exponents of the shipped inputs (ek = 3) the host
 // selects EXP_MODE = that integer and the power is formed by multiplication (<= 1 ulp from pow).
@@ -80,7 +89,7 @@ RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
   else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
   else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
   else if (EXP_MODE == 25) { pm1 = x * sqrt(x); p = pm1 * x; }  // e = 2.5 (run/RIPF133/input.dat): one sqrt, no pow
-  else { p = pow(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
+  else { p = rdc_pow(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
 }
 
 // =========================================================================================
@@ -314,11 +323,12 @@ struct Ripf {
   }
   static inline double exponent(const K& k) { return k.VF_exp; }
 
+  // Per point only the interpolated inputs and the transcendental results are kept (10 doubles instead of
+  // 20: the factored TET4 kernels hold 5 points at once); the select-and-multiply quantities are re-derived in
+  // coef(), where the compiler drops what the requested equation row does not use.
   struct Pt {
-    double HU, cc, fb, cc_dt, fb_dt;
-    double kappa_RT, delta_RT, lambda_RT, omicro_RT, eps_cc, eps_fb;
-    double Tau, dTau, Koppa, Koppa_dcc;
-    double Lom, Lom_dHU, Lom_dfb, Ome, Ome_dfb;
+    double HU, cc, fb, cc_dt, fb_dt, RT;
+    double kappa_RT, delta_RT, Tau, dTau;
   };
 
   template <int EXP_MODE>
@@ -326,17 +336,9 @@ struct Ripf {
     s.HU = u[0]; s.cc = u[1]; s.fb = u[2];
     s.cc_dt = aux[0]; s.fb_dt = aux[1];
     const double RT = aux[2];
+    s.RT = RT;
     s.kappa_RT = k.kappa * exp(-k.kappa_RT_c * RT);                                   // :486
     s.delta_RT = k.delta * (1.0 - exp(-k.delta_RT_a * RT - k.delta_RT_b * (RT * RT)));  // :487
-    s.lambda_RT = k.lambda * (RT * k.i_lambda_RT_r);                                     // :488
-    {
-      const double r = RT * k.i_omicro_RT_r;                                           // :489
-      const double x = 4.0 * (r - r * r);
-      s.omicro_RT = k.omicro * (x < 0.0 ? 0.0 : x);
-    }
-    s.eps_cc = 0.0; s.eps_fb = 0.0;                                                   // :491-496
-    if (s.cc_dt > k.phi_tol) s.eps_cc = k.phi_cc_B; else if (s.cc_dt < -k.phi_tol) s.eps_cc = k.phi_cc_D;
-    if (s.fb_dt > k.phi_tol) s.eps_fb = k.phi_fb_B; else if (s.fb_dt < -k.phi_tol) s.eps_fb = k.phi_fb_D;
     const double VF = k.VF_fixed + (s.cc + s.fb);                                     // :498-499
     s.Tau = 0.0; s.dTau = 0.0;
     if (VF < 1.0) {                                                                   // :503-514
@@ -346,6 +348,27 @@ struct Ripf {
       s.dTau = -k.VF_exp * pm1;
       if (s.Tau < k.VF_min) { s.Tau = 0.0; s.dTau = 0.0; }
     }
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& p, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    struct {
+      double HU, cc, fb, cc_dt, fb_dt, kappa_RT, delta_RT, lambda_RT, omicro_RT, eps_cc, eps_fb, Tau, dTau, Koppa, Koppa_dcc,
+          Lom, Lom_dHU, Lom_dfb, Ome, Ome_dfb;
+    } s;
+    s.HU = p.HU; s.cc = p.cc; s.fb = p.fb; s.cc_dt = p.cc_dt; s.fb_dt = p.fb_dt;
+    s.kappa_RT = p.kappa_RT; s.delta_RT = p.delta_RT; s.Tau = p.Tau; s.dTau = p.dTau;
+    const double RT = p.RT;
+    s.lambda_RT = k.lambda * (RT * k.i_lambda_RT_r);                                     // :488
+    {
+      const double r = RT * k.i_omicro_RT_r;                                           // :489
+      const double x = 4.0 * (r - r * r);
+      s.omicro_RT = k.omicro * (x < 0.0 ? 0.0 : x);
+    }
+    s.eps_cc = 0.0; s.eps_fb = 0.0;                                                   // :491-496
+    if (s.cc_dt > k.phi_tol) s.eps_cc = k.phi_cc_B; else if (s.cc_dt < -k.phi_tol) s.eps_cc = k.phi_cc_D;
+    if (s.fb_dt > k.phi_tol) s.eps_fb = k.phi_fb_B; else if (s.fb_dt < -k.phi_tol) s.eps_fb = k.phi_fb_D;
     s.Koppa = 0.0; s.Koppa_dcc = 0.0;                                                 // :516-523
     if (s.cc >= 0.0 && s.cc < 1.0) { s.Koppa = 4.0 * (s.cc - s.cc * s.cc); s.Koppa_dcc = 4.0 - 8.0 * s.cc; }
     s.Lom = s.Lom_dHU = s.Lom_dfb = 0.0; s.Ome = s.Ome_dfb = 0.0;                     // :525-561
@@ -366,11 +389,6 @@ struct Ripf {
         s.Ome_dfb = 4.0 - 8.0 * s.fb;
       }
     }
-  }
-
-  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
-    o.zero();
-    const double T = k.DT2;
     // HU equation, :566-574, :599-613
     o.R[0] = s.HU + T * (s.eps_cc * s.cc + s.eps_fb * s.fb + k.phi_cc * s.cc_dt + k.phi_fb * s.fb_dt);
     o.A[0][0] = 1.0;
@@ -589,16 +607,23 @@ struct Adpm {
     for (int d = 0; d < 3; d++) { GF[2][d] = tA[d]; GF[3][d] = tT[d]; }
   }
 
-  struct Pt {
-    double PrP, A_b, Tau;
-    double TrA, dTrA, TrT, dTrT, PiP;
-    double SDA, dSDA, decA, difA, t1A, t2A;
-    double SDT, dSDT, decT, difT, t1T, t2T;
-  };
+  // Only the interpolated unknowns are kept per point: the piecewise rates are a few compares each, and
+  // evaluating them inside coef() (where the compiler drops what the requested equation row does not use)
+  // keeps the per-point state at 3 doubles instead of 20 -- the factored TET4 kernels hold 5 points at once.
+  struct Pt { double PrP, A_b, Tau; };
 
   template <int EXP_MODE>
-  RDC_HD static void point(const K& k, const double* u, const double* /*aux*/, Pt& s) {
+  RDC_HD static void point(const K&, const double* u, const double* /*aux*/, Pt& s) {
     s.PrP = u[0]; s.A_b = u[1]; s.Tau = u[2];
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& p, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    struct {
+      double PrP, A_b, Tau, TrA, dTrA, TrT, dTrT, PiP, SDA, dSDA, decA, difA, t1A, t2A, SDT, dSDT, decT, difT, t1T, t2T;
+    } s;
+    s.PrP = p.PrP; s.A_b = p.A_b; s.Tau = p.Tau;
     s.TrA = pw_Tr(s.A_b, k.transform_A_b, k.iw_trA_up, k.iw_trA_dn); s.dTrA = pw_dTr(s.A_b, k.transform_A_b, k.iw_trA_up, k.iw_trA_dn);
     s.TrT = pw_Tr(s.Tau, k.transform_Tau, k.iw_trT_up, k.iw_trT_dn); s.dTrT = pw_dTr(s.Tau, k.transform_Tau, k.iw_trT_up, k.iw_trT_dn);
     s.PiP = pw_Pi(s.PrP, k.decay_PrP);
@@ -608,11 +633,6 @@ struct Adpm {
     s.SDT = pw_SD(s.Tau, k.produce_Tau, k.iw_prodT); s.dSDT = pw_dSD(s.Tau, k.produce_Tau, k.iw_prodT);
     s.decT = pw_Pi(s.Tau, k.decay_Tau); s.difT = pw_Pi(s.Tau, k.diffuse_Tau);
     s.t1T = pw_Pi(s.Tau, k.taxis1_Tau); s.t2T = pw_Pi(s.A_b, k.taxis2_Tau);      // :530
-  }
-
-  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
-    o.zero();
-    const double T = k.DT2;
     // PrP, :497-504 and :537-556
     o.R[0] = s.PrP + T * (-s.TrA * s.PrP - s.TrT * s.PrP - s.PiP * s.PrP);
     o.A[0][0] = 1.0 - T * (-s.TrA - s.TrT - s.PiP);
@@ -688,39 +708,44 @@ struct Proteas {
   }
   static inline double exponent(const K& k) { return k.p_RT_e; }
 
+  // per point: the unknowns and the transcendental results only (see Ripf::Pt)
   struct Pt {
     double hos, tum, nec, vsc, oed;
-    double Kap, hp, dhp, hRT, tp, dtp, tRT, nclr, dnclr, dvp, oRT, oclr;
+    double hRT, tRT, nclr, dnclr, oRT;
   };
 
   template <int EXP_MODE>
   RDC_HD static void point(const K& k, const double* u, const double* aux, Pt& s) {
     s.hos = u[0]; s.tum = u[1]; s.nec = u[2]; s.vsc = u[3]; s.oed = u[4];
     const double RTD = aux[0];                                               // masked interpolation, see above
-    const double Tt = s.hos + s.tum + s.nec + s.vsc;                         // :490
-    double Kap = 1.0 - Tt / k.T_max;                                         // :491-492
-    Kap = (Kap > 0.0 ? Kap : 0.0);
-    Kap = (Kap < 1.0 ? Kap : 1.0);
-    s.Kap = Kap;
-    const double dK = -1.0 / k.T_max;                                        // :493
-    const double Hh = (s.vsc - k.u_h > 0.0 ? 1.0 : 0.0), Hc = (s.vsc - k.u_c > 0.0 ? 1.0 : 0.0);
-    s.hp = k.rho_h * Kap * Hh; s.dhp = k.rho_h * dK * Hh;                    // :495-496
     s.hRT = k.delta_h * (1.0 - exp(-k.a_RT_h * RTD - k.b_RT_h * (RTD * RTD)));  // :497
-    s.tp = k.rho_c * Kap * Hc; s.dtp = k.rho_c * dK * Hc;                    // :500-501
     s.tRT = k.delta_c * (1.0 - exp(-k.a_RT_c * RTD - k.b_RT_c * (RTD * RTD)));  // :502
     const double arg = k.k_n * s.vsc - k.u_n;
     s.nclr = k.psi_n * (1.0 - tanh(arg));                                    // :506
     const double ch = cosh(arg);
     s.dnclr = k.psi_n * -k.k_n / (ch * ch);                                  // :507
-    s.dvp = k.rho_v * dK * s.tum;                                            // :510
     const double x = RTD * k.i_RT_max;
-    s.oRT = k.xi_e * (EXP_MODE == 1 ? x : pow(x, k.p_RT_e));                 // :515
-    s.oclr = k.psi_e * (1.0 - (s.vsc - k.u_e > 0.0 ? 1.0 : 0.0));            // :516
+    s.oRT = k.xi_e * (EXP_MODE == 1 ? x : rdc_pow(x, k.p_RT_e));             // :515
   }
 
-  RDC_HD static void coef(const K& k, const Pt& s, C& o) {
+  RDC_HD static void coef(const K& k, const Pt& p, C& o) {
     o.zero();
-    const double T = k.DT2, dK = -1.0 / k.T_max;
+    const double T = k.DT2, dK = -1.0 / k.T_max;                             // :493
+    struct { double hos, tum, nec, vsc, oed, Kap, hp, dhp, hRT, tp, dtp, tRT, nclr, dnclr, dvp, oRT, oclr; } s;
+    s.hos = p.hos; s.tum = p.tum; s.nec = p.nec; s.vsc = p.vsc; s.oed = p.oed;
+    s.hRT = p.hRT; s.tRT = p.tRT; s.nclr = p.nclr; s.dnclr = p.dnclr; s.oRT = p.oRT;
+    {
+      const double Tt = s.hos + s.tum + s.nec + s.vsc;                       // :490
+      double Kap = 1.0 - Tt / k.T_max;                                       // :491-492
+      Kap = (Kap > 0.0 ? Kap : 0.0);
+      Kap = (Kap < 1.0 ? Kap : 1.0);
+      s.Kap = Kap;
+      const double Hh = (s.vsc - k.u_h > 0.0 ? 1.0 : 0.0), Hc = (s.vsc - k.u_c > 0.0 ? 1.0 : 0.0);
+      s.hp = k.rho_h * Kap * Hh; s.dhp = k.rho_h * dK * Hh;                  // :495-496
+      s.tp = k.rho_c * Kap * Hc; s.dtp = k.rho_c * dK * Hc;                  // :500-501
+      s.dvp = k.rho_v * dK * s.tum;                                          // :510
+      s.oclr = k.psi_e * (1.0 - (s.vsc - k.u_e > 0.0 ? 1.0 : 0.0));          // :516
+    }
     const double hn = k.nu_h * s.nec, tn = k.nu_c * s.nec;                   // :498,503
     const double np_ = k.nu_h * s.hos + k.nu_c * s.tum + k.nu_v * s.vsc;     // :505
     const double vp = k.rho_v * s.Kap * s.tum, vn = k.nu_v * s.nec;          // :509,511
