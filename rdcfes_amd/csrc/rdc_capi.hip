@@ -36,6 +36,7 @@ struct rdc_ctx {
   int opt_grid = 0;     // persistent grid size of the pipelined kernel (0 = 2 workgroups per CU)
   int opt_sched = 1;    // LDS-conflict-aware pair schedule (takes effect at the next rdc_mesh_upload)
   int opt_special = 1;  // allow parameter-sparsity kernel variants
+  int opt_slim = 0;     // PIHNA: slim per-point state (re-derived per equation row); with occupancy=3 three waves per SIMD
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
   // device mesh data
@@ -185,8 +186,10 @@ template <class M, class P>
 hipError_t launch_specialised(const LaunchArgs& a, const typename M::K& k, const P&) { return launch_rd<M>(a, k); }
 template <>
 hipError_t launch_specialised<Pihna, rdc_pihna_params>(const LaunchArgs& a, const Pihna::K& k, const rdc_pihna_params& p) {
-  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && PihnaNoCellTransport::applies(p))
+  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && PihnaNoCellTransport::applies(p)) {
+    if (a.opt_slim && a.exp_mode == 3) return launch_tet4_fast<PihnaNoCellTransportSlim>(a, k);
     return launch_tet4_fast<PihnaNoCellTransport>(a, k);
+  }
   return launch_rd<Pihna>(a, k);
 }
 
@@ -219,6 +222,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_ablate = c->opt_ablate;
   a.opt_kernel = c->opt_kernel;
   a.opt_special = c->opt_special;
+  a.opt_slim = c->opt_slim;
   a.opt_xcd = c->opt_xcd;
   a.opt_grid = c->opt_grid;
   a.opt_pf = c->opt_pf;
@@ -352,6 +356,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     c->opt_block = value;
   }
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
+  else if (!std::strcmp(key, "slim")) c->opt_slim = value;
   else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
   else if (!std::strcmp(key, "grid")) c->opt_grid = value;

@@ -271,6 +271,33 @@ struct PihnaNoCellTransport : Pihna {
   RDC_HD static constexpr bool hasRG(int a, int k) { return a == 3 && k == 2; }
 };
 
+// The same with a slim per-point state: only the five interpolated unknowns are kept per point (5 x 5 doubles
+// instead of 5 x 11) and Tau, Ve, Ua are re-derived inside coef() for the equation row that needs them -- more
+// FP64 work per pair (1,774 vs 1,374 VALU instructions), but the kernel then fits three waves per SIMD (168
+// registers, 44 B of scratch).  Cube exponent only (the host selects it for the shipped exponent 3).
+// EXPERIMENTAL, rdc_set_option("slim", 1) + ("occupancy", 3): measured 2.95 ms vs 2.93 ms for the default on
+// K(119) -- the third wave buys 15% (3.46 -> 2.95 ms at equal work), the re-derivation costs it again
+// (profiles/r01e_ab_slim_occupancy3.txt).  Kept as the starting point for a cheaper re-derivation.
+struct PihnaNoCellTransportSlim : PihnaNoCellTransport {
+  struct Pt { double n, c, h, v, a; };
+  template <int EXP_MODE>
+  RDC_HD static void point(const K&, const double* u, const double*, Pt& s) {
+    s.n = u[0]; s.c = u[1]; s.h = u[2]; s.v = u[3]; s.a = u[4];
+  }
+  RDC_HD static void coef(const K& k, const Pt& p, C& o) {
+    double u[5] = {p.n, p.c, p.h, p.v, p.a};
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque copies: without them the compiler hoists the derivation out of the equation-row loop and keeps all
+    // of it live again (256 registers + 252 B of scratch instead of 186 registers)
+#pragma unroll
+    for (int v = 0; v < 5; v++) asm volatile("" : "+v"(u[v]));
+#endif
+    Pihna::Pt full;
+    Pihna::point<3>(k, u, nullptr, full);
+    Pihna::coef(k, full, o);
+  }
+};
+
 // =========================================================================================
 // RIPF: unknowns (HU, cc, fb); aux nodal (cc_dtime, fb_dtime, RT_total);
 // gradient fields k: 0 = fb, 1 = HU, 2 = RT_total (normalised to unit length, :481-484)

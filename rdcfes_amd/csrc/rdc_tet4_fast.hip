@@ -733,6 +733,9 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
         return hipGetLastError();
       }
     }
+    if constexpr (std::is_same<M, PihnaNoCellTransportSlim>::value) {
+      if (a.opt_occ == 3) { RDC_RG5(3, false); return hipGetLastError(); }
+    }
     if (a.stamps && std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) RDC_RG5(2, true);
     else if (a.opt_occ == 1) RDC_RG5(1, false);
     else RDC_RG5(2, false);
@@ -820,6 +823,7 @@ hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k) {
 
 template hipError_t launch_tet4_fast<Pihna>(const LaunchArgs&, const Pihna::K&);
 template hipError_t launch_tet4_fast<PihnaNoCellTransport>(const LaunchArgs&, const PihnaNoCellTransport::K&);
+template hipError_t launch_tet4_fast<PihnaNoCellTransportSlim>(const LaunchArgs&, const PihnaNoCellTransportSlim::K&);
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
 template hipError_t launch_tet4_fast<Adpm>(const LaunchArgs&, const Adpm::K&);

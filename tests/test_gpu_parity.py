@@ -329,3 +329,21 @@ def test_two_rank_partitioned_assembly():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(err < TOL for _, err in res), res
+
+
+@pytest.mark.parametrize("opts", [{"slim": 1, "occupancy": 3}, {"slim": 1}, {"kernel": 3}, {"kernel": 4}, {"kernel": 2},
+                                  {"kernel": 1}, {"occupancy": 1}, {"xcd": 1}, {"prefetch": 16}, {"specialise": 0}])
+def test_pihna_option_sets(oracle, opts):
+    """Every non-default kernel selection (rdc_set_option) of the PIHNA/TET4 path stays on the oracle."""
+    conn, xyz = synth.kuhn_tet_mesh(9, order="lex")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    with AssemblyContext(0) as ctx:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val, rhs = ctx.csr_download()
+    assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
