@@ -11,47 +11,58 @@ import torch.distributed as dist
 
 
 class HaloExchange:
+    """All peers share ONE send and ONE receive buffer (per-peer slices of them are what is sent): a step costs one
+    gather kernel, one grouped send/recv and one scatter kernel whatever the number of neighbours -- at 8 GPUs
+    the assembly kernel is ~0.4 ms, so per-peer launches would be a visible fraction of the step."""
+
     def __init__(self, lp, nvar: int, device, group=None):
         self.group = group
         self.nvar = nvar
         self.rank = lp.rank
         self.peers = sorted(set(lp.send_ids) | set(lp.recv_ids))
         dev = torch.device(device)
-        self.send_idx = {q: torch.as_tensor(lp.send_ids[q], dtype=torch.long, device=dev) for q in lp.send_ids}
-        self.recv_idx = {q: torch.as_tensor(lp.recv_ids[q], dtype=torch.long, device=dev) for q in lp.recv_ids}
-        self.send_buf = {q: torch.empty((i.numel(), nvar), dtype=torch.float64, device=dev) for q, i in self.send_idx.items()}
-        self.recv_buf = {q: torch.empty((i.numel(), nvar), dtype=torch.float64, device=dev) for q, i in self.recv_idx.items()}
-        self.bytes_per_step = 8 * nvar * sum(i.numel() for i in self.send_idx.values())
+        as_idx = lambda a: torch.as_tensor(a, dtype=torch.long, device=dev)
+        self.send_peers = [q for q in self.peers if q in lp.send_ids and len(lp.send_ids[q])]
+        self.recv_peers = [q for q in self.peers if q in lp.recv_ids and len(lp.recv_ids[q])]
+        cat = lambda ids, qs: as_idx([i for q in qs for i in ids[q]]) if qs else as_idx([])
+        self.send_idx = cat(lp.send_ids, self.send_peers)
+        self.recv_idx = cat(lp.recv_ids, self.recv_peers)
+        self.send_buf = torch.empty((self.send_idx.numel(), nvar), dtype=torch.float64, device=dev)
+        self.recv_buf = torch.empty((self.recv_idx.numel(), nvar), dtype=torch.float64, device=dev)
+        self.bytes_per_step = 8 * nvar * int(self.send_idx.numel())
         # gloo cannot move device tensors: stage through host buffers (test rigs with one GPU only;
         # the production backend is "nccl" = RCCL, which sends the device buffers directly)
         self.host_staged = dev.type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo"
         if self.host_staged:
-            self.send_host = {q: torch.empty_like(b, device="cpu").pin_memory() for q, b in self.send_buf.items()}
-            self.recv_host = {q: torch.empty_like(b, device="cpu").pin_memory() for q, b in self.recv_buf.items()}
+            self.send_host = torch.empty_like(self.send_buf, device="cpu").pin_memory()
+            self.recv_host = torch.empty_like(self.recv_buf, device="cpu").pin_memory()
+        sb = self.send_host if self.host_staged else self.send_buf
+        rb = self.recv_host if self.host_staged else self.recv_buf
+
+        def views(buf, ids, qs):
+            out, o = {}, 0
+            for q in qs:
+                n = len(ids[q])
+                out[q] = buf[o:o + n]
+                o += n
+            return out
+        self.send_view = views(sb, lp.send_ids, self.send_peers)
+        self.recv_view = views(rb, lp.recv_ids, self.recv_peers)
 
     def exchange(self, u: torch.Tensor):
         """u: [n_node_local][nvar]; owned rows are read, ghost rows are overwritten in place."""
-        if not self.peers:
+        if not self.send_peers and not self.recv_peers:
             return
-        ops = []
-        rbuf = self.recv_host if self.host_staged else self.recv_buf
-        sbuf = self.send_host if self.host_staged else self.send_buf
-        for q in self.peers:
-            if q in self.recv_idx:
-                ops.append(dist.P2POp(dist.irecv, rbuf[q], q, group=self.group))
-        for q in self.peers:
-            if q in self.send_idx:
-                torch.index_select(u, 0, self.send_idx[q], out=self.send_buf[q])
-                if self.host_staged:
-                    self.send_host[q].copy_(self.send_buf[q], non_blocking=True)
-        if self.host_staged:
-            torch.cuda.current_stream().synchronize()
-        for q in self.peers:
-            if q in self.send_idx:
-                ops.append(dist.P2POp(dist.isend, sbuf[q], q, group=self.group))
+        if self.send_idx.numel():
+            torch.index_select(u, 0, self.send_idx, out=self.send_buf)
+            if self.host_staged:
+                self.send_host.copy_(self.send_buf, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+        ops = [dist.P2POp(dist.irecv, self.recv_view[q], q, group=self.group) for q in self.recv_peers]
+        ops += [dist.P2POp(dist.isend, self.send_view[q], q, group=self.group) for q in self.send_peers]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        for q, idx in self.recv_idx.items():
+        if self.recv_idx.numel():
             if self.host_staged:
-                self.recv_buf[q].copy_(self.recv_host[q], non_blocking=True)
-            u.index_copy_(0, idx, self.recv_buf[q])
+                self.recv_buf.copy_(self.recv_host, non_blocking=True)
+            u.index_copy_(0, self.recv_idx, self.recv_buf)
