@@ -274,6 +274,20 @@ int rdc_ripf_check_solution(rdc_ctx* ctx, const rdc_ripf_check_params* p, double
 int rdc_solid_post_process(rdc_ctx* ctx, const rdc_solid_params* p, double* pressure, double* von_mises,
                            double* fibre_current);
 
+/* save_solution of PIHNA, src/pihna.C:842-976 ("CSV volume integrals"): the four element-volume
+ * sums of the CSV line -- an element counts when ALL its nodes have (c+h), n, v, (n+c+h+v)/cells_max_capacity inside
+ * the closed range -- over the first n_elem elements of the context (pass the number of elements the rank owns, or
+ * -1 for all; upstream loops over every active element on rank 0), read from RDC_FIELD_OLD_SOLUTION (5 unknowns).
+ * out[4] = {ACTIVE_TUMOR_VOLUME, NECROTIC_VOLUME, VASCULARITY_VOLUME, TOTAL_CELL_VOLUME}; with several ranks add them. */
+typedef struct rdc_pihna_ranges {
+  double active_tumor_min, active_tumor_max;   /* "range/active_tumor/min,max" */
+  double necrotic_min, necrotic_max;           /* "range/necrotic/min,max"     */
+  double vascularity_min, vascularity_max;     /* "range/vascularity/min,max"  */
+  double total_cell_min, total_cell_max;       /* "range/total_cell/min,max"   */
+  double cells_max_capacity;                   /* "cells_max_capacity"         */
+} rdc_pihna_ranges;
+int rdc_pihna_volume_integrals(rdc_ctx* ctx, const rdc_pihna_ranges* r, int64_t n_elem, double* out4);
+
 /* ---- instrumentation ---- */
 /* when enabled every rdc_assemble_* brackets its dominant kernel(s) -- the assembly kernel, or all
  * colour launches; not the small node-record pack -- with HIP events on the context stream */

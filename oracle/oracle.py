@@ -176,6 +176,17 @@ def solid_post_process(elem_type, conn, xyz, xyz_undeformed, elem_fibre, elem_ma
     return pr, vm, fc
 
 
+def pihna_volume_integrals(elem_type, conn, xyz, u, ranges, n_elem=None):
+    conn = np.ascontiguousarray(conn, dtype=np.uint32)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(4)
+    ne = conn.shape[0] if n_elem is None else n_elem
+    rc = lib().oracle_pihna_volume_integrals(int(elem_type), C.c_int64(ne), _p(conn, C.c_uint32), _p(xyz), _p(u), C.byref(ranges), _p(out))
+    assert rc == 0
+    return out
+
+
 def ripf_check_solution(params, sol, prev, rt):
     """-> (clamped solution, new prev, time derivative, rt with total, aux, RT_total_max)"""
     cp = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()

@@ -1230,6 +1230,52 @@ double oracle_ripf_check_solution(int64_t n, const rdc_ripf_check_params* p, dou
   return RT_total_max;
 }
 
+/* save_solution volume sums of PIHNA                                src/pihna.C:898-958
+ * u: [n_node][5]; elements [0, n_elem); out[4] = active tumour, necrotic, vascularity, total cell volumes.
+ * elem->volume() is restated as the sum of JxW of the element's rule. */
+int oracle_pihna_volume_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz, const double* u,
+                                  const rdc_pihna_ranges* r, double* out) {
+  const int nen = elem_type, nqp = oracle_nqp(elem_type);
+  if (nqp < 0) return 1;
+  double X[8 * 3], phi[8 * 8], dphi[8 * 8 * 3], JxW[8];
+  out[0] = out[1] = out[2] = out[3] = 0.0;
+  for (int64_t e = 0; e < n_elem; e++) {
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++)
+      for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+    oracle_fe_reinit(elem_type, X, phi, dphi, JxW);
+    double Volume = 0.0;
+    for (int q = 0; q < nqp; q++) Volume += JxW[q];
+    int consider;
+    consider = 1; /* :905-917 */
+    for (int n = 0; n < nen; n++) {
+      const double c_h_ = u[5 * (int64_t)c[n] + 1] + u[5 * (int64_t)c[n] + 2];
+      if (!(c_h_ >= r->active_tumor_min && c_h_ <= r->active_tumor_max)) { consider = 0; break; }
+    }
+    if (consider) out[0] += Volume;
+    consider = 1; /* :919-930 */
+    for (int n = 0; n < nen; n++) {
+      const double n_ = u[5 * (int64_t)c[n]];
+      if (!(n_ >= r->necrotic_min && n_ <= r->necrotic_max)) { consider = 0; break; }
+    }
+    if (consider) out[1] += Volume;
+    consider = 1; /* :932-943 */
+    for (int n = 0; n < nen; n++) {
+      const double v_ = u[5 * (int64_t)c[n] + 3];
+      if (!(v_ >= r->vascularity_min && v_ <= r->vascularity_max)) { consider = 0; break; }
+    }
+    if (consider) out[2] += Volume;
+    consider = 1; /* :945-958 */
+    for (int n = 0; n < nen; n++) {
+      const double* un = u + 5 * (int64_t)c[n];
+      const double T_ = (un[0] + un[1] + un[2] + un[3]) / r->cells_max_capacity;
+      if (!(T_ >= r->total_cell_min && T_ <= r->total_cell_max)) { consider = 0; break; }
+    }
+    if (consider) out[3] += Volume;
+  }
+  return 0;
+}
+
 /* check_solution negativity clamp, src/pihna.C:785-790 */
 void oracle_clamp_nonnegative(double* u, int64_t n) {
   for (int64_t i = 0; i < n; i++) if (u[i] < 0.0) u[i] = 0.0;

@@ -40,6 +40,8 @@ void oracle_adpm_element(int nen, int nqp, const double* phi, const double* dphi
                          const double* u, const double* tracts3, const rdc_adpm_params* P, double* Ke, double* Fe);
 void oracle_proteas_element(int nen, int nqp, const double* phi, const double* dphi, const double* JxW,
                             const double* u, const double* aux0, const rdc_proteas_params* P, double* Ke, double* Fe);
+int oracle_pihna_volume_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz, const double* u,
+                                  const rdc_pihna_ranges* r, double* out);
 void oracle_clamp_nonnegative(double* u, int64_t n);
 int oracle_solid_post_process(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
                               const double* xyz_undeformed, const double* elem_fibre, const int32_t* elem_material,

@@ -144,6 +144,12 @@ class AssemblyContext:
     def clamp_nonnegative(self, field):
         self._ck(self._lib.rdc_clamp_nonnegative(self._h, int(field)))
 
+    def pihna_volume_integrals(self, ranges, n_elem=-1):
+        """the four volume sums of PIHNA's CSV line (src/pihna.C:842-976) over the first n_elem elements"""
+        out = np.zeros(4)
+        self._ck(self._lib.rdc_pihna_volume_integrals(self._h, C.byref(ranges), int(n_elem), _dp(out)))
+        return out
+
     def solid_post_process(self, params):
         """SolidSystem::post_process -> (pressure [ne], von_mises [ne], fibre_current [ne][3])"""
         pr, vm, fc = np.empty(self.n_elem), np.empty(self.n_elem), np.empty((self.n_elem, 3))

@@ -706,6 +706,39 @@ int rdc_clamp_nonnegative(rdc_ctx* c, int field) {
   return RDC_OK;
 }
 
+int rdc_pihna_volume_integrals(rdc_ctx* c, const rdc_pihna_ranges* r, int64_t n_elem, double* out4) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!r || !out4) return fail(c, RDC_ERR_INVALID, "null argument");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (c->prep.nvar != 5) return fail(c, RDC_ERR_INVALID, "PIHNA volume integrals need nvar=5");
+  if (!c->field[RDC_FIELD_OLD_SOLUTION].p) return fail(c, RDC_ERR_STATE, "solution field not set");
+  if (n_elem < 0) n_elem = c->prep.n_elem;
+  if (n_elem > c->prep.n_elem) return fail(c, RDC_ERR_INVALID, "n_elem exceeds the mesh");
+  int rc = set_device(c);
+  if (rc) return rc;
+  int64_t grid = (n_elem + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  if ((rc = dev_alloc(c, c->wg_max, (size_t)grid * 4 * sizeof(double)))) return rc;
+  const MeshDev m = mesh_view(c);
+  if (c->prep.nen == 4)
+    hipLaunchKernelGGL((k_pihna_volumes<4>), dim3((unsigned)grid), dim3(256), 0, c->stream, m, n_elem,
+                       (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p, *r, (double*)c->wg_max.p);
+  else
+    hipLaunchKernelGGL((k_pihna_volumes<8>), dim3((unsigned)grid), dim3(256), 0, c->stream, m, n_elem,
+                       (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p, *r, (double*)c->wg_max.p);
+  RDC_HIP(c, hipGetLastError());
+  std::vector<double> h((size_t)grid * 4);
+  RDC_HIP(c, hipMemcpyAsync(h.data(), c->wg_max.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  for (int x = 0; x < 4; x++) {
+    double s = 0.0;
+    for (int64_t g = 0; g < grid; g++) s += h[(size_t)g * 4 + x];
+    out4[x] = s;
+  }
+  return RDC_OK;
+}
+
 int rdc_solid_post_process(rdc_ctx* c, const rdc_solid_params* p, double* pressure, double* von_mises,
                            double* fibre_current) {
   if (!c) return RDC_ERR_INVALID;

@@ -163,6 +163,50 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
   for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
 }
 
+// PIHNA save_solution volume sums (src/pihna.C:898-958): per-workgroup partial sums -> part[blockIdx.x][4]
+template <int NEN>
+static __global__ void __launch_bounds__(256)
+k_pihna_volumes(const MeshDev m, int64_t n_elem, const double* __restrict__ u, const rdc_pihna_ranges r,
+                double* __restrict__ part) {
+  __shared__ double red[4][256];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * 256) {
+    double X[NEN][3];
+    bool ok[4] = {true, true, true, true};
+#pragma unroll
+    for (int i = 0; i < NEN; i++) {
+      const int64_t n = m.conn[e * NEN + i];
+#pragma unroll
+      for (int d = 0; d < 3; d++) X[i][d] = m.xyz[3 * n + d];
+      const double n_ = u[5 * n], c_ = u[5 * n + 1], h_ = u[5 * n + 2], v_ = u[5 * n + 3];
+      const double ch = c_ + h_, T_ = (n_ + c_ + h_ + v_) / r.cells_max_capacity;
+      ok[0] = ok[0] && (ch >= r.active_tumor_min && ch <= r.active_tumor_max);
+      ok[1] = ok[1] && (n_ >= r.necrotic_min && n_ <= r.necrotic_max);
+      ok[2] = ok[2] && (v_ >= r.vascularity_min && v_ <= r.vascularity_max);
+      ok[3] = ok[3] && (T_ >= r.total_cell_min && T_ <= r.total_cell_max);
+    }
+    double vol = 0.0;  // elem->volume(): sum of JxW (exact for TET4 and for the trilinear HEX8 map)
+#pragma unroll 1
+    for (int q = 0; q < Ref<NEN>::NQP; q++) {
+      double N[NEN], G[NEN][3], W;
+      fe_point<NEN>(X, q, N, G, W);
+      vol += W;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) acc[x] += ok[x] ? vol : 0.0;
+  }
+#pragma unroll
+  for (int x = 0; x < 4; x++) red[x][threadIdx.x] = acc[x];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int x = 0; x < 4; x++) red[x][threadIdx.x] += red[x][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
 // RIPF check_solution (src/ripf.C:675-775): clamp, time-derivative system, fractionation schedule, prev := unclamped,
 // aux record of the next assembly; per-workgroup maxima of the total dose go to wg_max[blockIdx.x].
 static __global__ void __launch_bounds__(256)

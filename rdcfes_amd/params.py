@@ -63,6 +63,12 @@ class ProteasParams(C.Structure):
     _fields_ = [(f, _D) for f in _PROTEAS_FIELDS]
 
 
+class PihnaRanges(C.Structure):
+    """rdc_pihna_ranges: the "range/*" keys of save_solution, src/pihna.C:853-861."""
+    _fields_ = [(f, _D) for f in ("active_tumor_min", "active_tumor_max", "necrotic_min", "necrotic_max", "vascularity_min",
+                                  "vascularity_max", "total_cell_min", "total_cell_max", "cells_max_capacity")]
+
+
 class RipfCheckParams(C.Structure):
     """rdc_ripf_check_params: what check_solution reads, src/ripf.C:697-703."""
     _fields_ = [("time_step", _D), ("HU_min", _D), ("HU_max", _D), ("RT_broad_fractions", C.c_int32),
