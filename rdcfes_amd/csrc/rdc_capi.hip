@@ -56,6 +56,7 @@ struct rdc_ctx {
   bool solid_gather_ready = false;
   int opt_solid_kernel = 0;  // 0 = two-pass (default), 1 = coloured read-modify-write
   int opt_solid_split = 1;   // two-pass, pass 1: 1 = one thread per element row (default; measured faster), 0 = HEX8 row columns split between two threads
+  int opt_solid_store = 0;   // two-pass, pass 1 diagnostics (see SolidArgs::store_mode)
   int opt_solid_gather = 0;  // two-pass, pass 2: 0 = stores staged through LDS, 1 = direct 24-byte pieces
   int32_t n_materials = 0;
   int64_t n_sides = 0;
@@ -363,6 +364,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "prefetch")) c->opt_pf = value;
   else if (!std::strcmp(key, "solid_gather")) c->opt_solid_gather = value ? 1 : 0;
   else if (!std::strcmp(key, "solid_split")) c->opt_solid_split = value ? 1 : 0;
+  else if (!std::strcmp(key, "solid_store")) c->opt_solid_store = value;
   else if (!std::strcmp(key, "solid_kernel")) {
     if (value != 0 && value != 1) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (two-pass) or 1 (coloured)");
     c->opt_solid_kernel = value;
@@ -635,6 +637,7 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   a.kernel = c->opt_solid_kernel;
   a.gather = c->opt_solid_gather;
   a.split = c->opt_solid_split;
+  a.store_mode = c->opt_solid_store;
   a.nblocks = c->prep.bptr[(size_t)c->prep.n_owned];
   if (a.kernel == 0) {
     if (!c->solid_gather_ready) {  // one-time: gather lists and the element-matrix buffers

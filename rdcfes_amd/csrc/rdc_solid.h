@@ -29,6 +29,7 @@ struct SolidArgs {
   const uint32_t* gsrc;
   const int32_t* brow;
   int split;                   // pass 1: 1 = one thread per element row (default), 0 = columns of a HEX8 row split between two threads
+  int store_mode;              // pass 1 diagnostics: 0 = staged stores (default), 1 = direct per-thread stores, 2 = none (timing only)
   int gather;                  // pass 2: 0 = stores staged through LDS (runs of consecutive doubles), 1 = 24-byte pieces
 };
 hipError_t launch_solid(const SolidArgs& a);

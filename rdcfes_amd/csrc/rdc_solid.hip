@@ -348,7 +348,7 @@ template <int NEN, bool JAC, bool SYM, int JS>
 __global__ void __launch_bounds__(128 * JS)
 k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __restrict__ fibre,
              const int32_t* __restrict__ elem_material, const rdc_solid_material* __restrict__ materials,
-             double pseudo_time, double* __restrict__ ke, double* __restrict__ fe) {
+             double pseudo_time, double* __restrict__ ke, double* __restrict__ fe, const int store_mode) {
   using C = SolidCfg<NEN>;
   using L = SolidLds<NEN>;
   constexpr int NB = NEN * 9;  // doubles of one row (node i, all j) of the element matrix
@@ -547,6 +547,18 @@ k_solid_elem(const MeshDev m, const double* __restrict__ Xu, const double* __res
     f[0] = re[0]; f[1] = re[1]; f[2] = re[2];
   }
   if (!JAC) return;
+  // diagnostic store modes (timing only): 1 = each thread stores its own row straight from registers (576-byte
+  // stride between lanes), 2 = no element-matrix stores at all
+  if (store_mode == 2) return;
+  if (store_mode == 1) {
+    if (live) {
+      rdc_v2d* dst = reinterpret_cast<rdc_v2d*>(ke + (e * NEN + li) * NB + jh * NJ * 9);
+      const double* a0 = &acc[0][0][0];
+#pragma unroll
+      for (int x = 0; x < NJ * 9 / 2; x++) { rdc_v2d v; v.x = a0[2 * x]; v.y = a0[2 * x + 1]; __builtin_nontemporal_store(v, dst + x); }
+    }
+    return;
+  }
   // ---- phase 3: rows -> LDS -> contiguous 16-byte stores -------------------------------------------
   constexpr int EPH = C::EPB / C::HALVES;  // elements per staging pass
 #pragma unroll 1
@@ -662,7 +674,7 @@ static void launch_two_pass(const SolidArgs& a) {
   const unsigned grid = (unsigned)((a.m.n_elem + SolidCfg<NEN>::EPB - 1) / SolidCfg<NEN>::EPB);
 #define RDC_SOLID_ELEM(JAC, SYM, JS)                                                                                \
   hipLaunchKernelGGL((k_solid_elem<NEN, JAC, SYM, JS>), dim3(grid), dim3(128 * JS), 0, a.stream, a.m, a.Xu, a.fibre, \
-                     a.elem_material, a.materials, a.params.pseudo_time, a.ke, a.fe)
+                     a.elem_material, a.materials, a.params.pseudo_time, a.ke, a.fe, a.store_mode)
   constexpr int JSD = (NEN == 8) ? 2 : 1;
   if (!a.request_jacobian) RDC_SOLID_ELEM(false, false, 1);
   else if (a.params.use_symmetry) RDC_SOLID_ELEM(true, true, JSD);
