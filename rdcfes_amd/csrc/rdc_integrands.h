@@ -155,7 +155,8 @@ struct Pihna {
     double Tau, dT;            // crowding and its (common) derivative          :444-472
     double Ve, rV;             // vascular fraction and 1/(c+h+v) (0 in the clamped branches):
                                // Ve__dc = Ve__dh = -Ve*rV, Ve__dv = (1-Ve)*rV    :474-499
-    double Ua, Ua_da;          // cytokine uptake                               :501-502
+    // the cytokine uptake Ua, Ua_da (:501-502) is used by the v equation only: it is derived inside coef(), so it
+    // does not occupy 5 points x 2 doubles of registers while the other four equation rows are evaluated
   };
 
   template <int EXP_MODE>
@@ -176,9 +177,6 @@ struct Pihna {
     if (Ve_ <= 0.0) { s.Ve = 0.0; s.rV = 0.0; }
     else if (Ve_ >= 1.0) { s.Ve = 1.0; s.rV = 0.0; }
     else { s.Ve = Ve_; s.rV = rchv; }
-    const double raK = rcp(s.a + k.Ka);
-    s.Ua = s.a * raK;
-    s.Ua_da = raK - s.Ua * raK;
   }
 
   // coefficients of equation row `a` only would be enough for a row kernel, but the full set is
@@ -232,15 +230,17 @@ struct Pihna {
     o.D[2][2] = T * dif_h * s.Tau;
     o.D[2][3] = T * tax_h * s.Tau * s.h;
     // ---- v equation, :548-556 and :686-724   (gradient fields: 2 = v, 3 = a)
-    const double pv = k.prod_v * s.dT * s.Ua * s.v;
-    o.R[3] = s.v + T * (k.prod_v * s.Tau * s.Ua * s.v - k.nec_v * s.v * s.n);
+    const double raK = rcp(s.a + k.Ka);                                          // :501-502
+    const double Ua = s.a * raK, Ua_da = raK - Ua * raK;
+    const double pv = k.prod_v * s.dT * Ua * s.v;
+    o.R[3] = s.v + T * (k.prod_v * s.Tau * Ua * s.v - k.nec_v * s.v * s.n);
     o.RG[3][2] = -T * dif_v * s.Tau;
     o.RG[3][3] = -T * tax_v * s.Tau * s.v;
     o.A[3][0] = -T * (pv - k.nec_v * s.v);
     o.A[3][1] = -T * pv;
     o.A[3][2] = -T * pv;
     o.A[3][3] = 1.0 - T * (pv - k.nec_v * s.n);
-    o.A[3][4] = -T * (k.prod_v * s.Tau * s.Ua_da * s.v);
+    o.A[3][4] = -T * (k.prod_v * s.Tau * Ua_da * s.v);
     {
       const double bv = T * dif_v * s.dT, ba = T * tax_v * s.dT * s.v;
       for (int b = 0; b < 4; b++) { o.B[3][b][2] = bv; o.B[3][b][3] = ba; }
