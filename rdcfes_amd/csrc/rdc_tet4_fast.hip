@@ -643,7 +643,7 @@ struct RmwSink {
 };
 
 template <class M, int EXP_MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)  // two waves per SIMD: 292 registers (one wave) ran 2x slower than a few spills
 k_tet4_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count, const double* __restrict__ rec,
                 const double* __restrict__ elem, double* __restrict__ val, double* __restrict__ rhs) {
   constexpr int NV = M::NV;

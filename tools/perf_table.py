@@ -33,7 +33,7 @@ def run(name, nen, conn, xyz, nv, setup, call, scatter, reps=5, n_in=None, solid
                           "B_alg_per_elem": round(B / conn.shape[0], 1), "GBps_alg": round(B / ms / 1e6, 1), "frac_of_8TBps": round(B / ms / 1e6 / 8000, 4),
                           "colours": ctx.n_colours(), "prep_s": round(prep, 2)}), flush=True)
 
-which = sys.argv[1:] or ["pihna55", "pihna119", "ripf94", "hcc_tet", "hcc126", "solid63", "pihna119_random"]
+which = sys.argv[1:] or ["pihna55", "pihna119", "ripf94", "hcc_tet", "adpm94", "proteas94", "hcc126", "adpm100hex", "solid63", "solid126", "solid60tet", "pihna119_random"]
 for w in which:
     if w.startswith("pihna"):
         order = "random" if w.endswith("random") else "lex"
