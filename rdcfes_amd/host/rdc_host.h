@@ -135,6 +135,7 @@ class System {
   // dof = node * n_vars + var (libMesh variable-group numbering)
   NumericVector solution, current_local_solution;
   Number current_solution(dof_id_type dof) const { return current_local_solution((int64_t)dof); }
+  bool elemental = false;  // CONSTANT MONOMIAL variables (one value per element): "Tracts", fibres
   virtual void init(int64_t n_nodes) {
     solution.init(n_nodes * n_vars());
     current_local_solution.init(n_nodes * n_vars());
@@ -203,7 +204,7 @@ class EquationSystems {
   // es.init(): DoF numbering, sparsity pattern, vector allocation (src/pihna.C:48)
   void init() {
     for (auto& kv : systems_) {
-      kv.second->init(mesh_.n_nodes());
+      kv.second->init(kv.second->elemental ? mesh_.n_elem() : mesh_.n_nodes());
       if (auto* t = dynamic_cast<TransientLinearImplicitSystem*>(kv.second.get())) {
         rdc_ctx* c = context(t->name(), (int)t->n_vars());
         int64_t n_rows = 0, nnz = 0;
@@ -357,6 +358,86 @@ inline void assemble_hcc(EquationSystems& es, const std::string& system_name) {
   check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.old_local_solution.raw().data(), system.old_local_solution.size()), "old solution");
   check(c, rdc_assemble_hcc(c, &p), "rdc_assemble_hcc");
   detail::pull_results(c, system);
+}
+
+// src/adpm.C:324-652: reads the elemental "Tracts" system (3 variables per element, :448-453) and system.time
+inline void assemble_adpm(EquationSystems& es, const std::string& system_name) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  if (system.n_vars() != 3) throw std::runtime_error("assemble_adpm: system must have 3 variables (PrP,A_b,Tau)");
+  System& tracts = es.get_system<System>("Tracts");
+  const Parameters& P = es.parameters;
+  rdc_adpm_params p{};
+  p.time_step = detail::getR(P, "time_step");
+  p.time = system.time;
+  p.decay_PrP_time_exponent = detail::getR(P, "decay/PrP/time_exponent");
+  auto triple = [&](double* dst, const std::string& key, const char* kind) {
+    dst[0] = detail::getR(P, key.c_str());
+    dst[1] = detail::getR(P, (key + "/" + kind + "/0").c_str());
+    dst[2] = detail::getR(P, (key + "/" + kind + "/1").c_str());
+  };
+  auto trapezoid = [&](double* dst, const std::string& key) {
+    dst[0] = detail::getR(P, key.c_str());
+    for (int i = 0; i < 4; i++) dst[1 + i] = detail::getR(P, (key + "/trapezoid/" + std::to_string(i)).c_str());
+  };
+  triple(p.decay_PrP, "decay/PrP", "pulse");
+  trapezoid(p.transform_A_b, "transform/A_b"); trapezoid(p.transform_Tau, "transform/Tau");
+  triple(p.diffuse_A_b, "diffuse/A_b", "pulse"); triple(p.taxis1_A_b, "taxis_1/A_b", "pulse"); triple(p.taxis2_A_b, "taxis_2/A_b", "pulse");
+  triple(p.produce_A_b, "produce/A_b", "sigmoid"); triple(p.decay_A_b, "decay/A_b", "pulse");
+  triple(p.diffuse_Tau, "diffuse/Tau", "pulse"); triple(p.taxis1_Tau, "taxis_1/Tau", "pulse"); triple(p.taxis2_Tau, "taxis_2/Tau", "pulse");
+  triple(p.produce_Tau, "produce/Tau", "sigmoid"); triple(p.decay_Tau, "decay/Tau", "pulse");
+  p.taxis_A_b_angle = detail::getR(P, "taxis/A_b/angle");  // radians: input() stores degrees_to_radians(...), src/adpm.C:193
+  p.taxis_Tau_angle = detail::getR(P, "taxis/Tau/angle");
+  rdc_ctx* c = es.context(system_name, 3);
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.old_local_solution.raw().data(), system.old_local_solution.size()), "old solution");
+  check(c, rdc_field_upload(c, RDC_FIELD_ELEM_TRACTS, tracts.solution.raw().data(), tracts.solution.size()), "tracts");
+  check(c, rdc_assemble_adpm(c, &p), "rdc_assemble_adpm");
+  detail::pull_results(c, system);
+}
+
+// src/proteas.C:338-705: reads the nodal "AUX" system (HU, RTD)
+inline void assemble_proteas_model(EquationSystems& es, const std::string& system_name) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  if (system.n_vars() != 5) throw std::runtime_error("assemble_proteas_model: system must have 5 variables");
+  System& AUX = es.get_system<System>("AUX");
+  const Parameters& P = es.parameters;
+  rdc_proteas_params p{};
+  p.time_step = detail::getR(P, "time_step");
+  p.cells_total_capacity = detail::getR(P, "cells/total_capacity"); p.RT_max_dosage = detail::getR(P, "radiotherapy/max_dosage");
+  p.host_proliferation = detail::getR(P, "host/proliferation"); p.host_vsc_threshold = detail::getR(P, "host/vsc_threshold");
+  p.host_RT_death_rate = detail::getR(P, "host/RT_death_rate"); p.host_RT_exp_a = detail::getR(P, "host/RT_exp_a");
+  p.host_RT_exp_b = detail::getR(P, "host/RT_exp_b"); p.host_necrosis_rate = detail::getR(P, "host/necrosis_rate");
+  p.tumour_diffusion = detail::getR(P, "tumour/diffusion"); p.tumour_diffusion_host = detail::getR(P, "tumour/diffusion_host");
+  p.tumour_proliferation = detail::getR(P, "tumour/proliferation"); p.tumour_vsc_threshold = detail::getR(P, "tumour/vsc_threshold");
+  p.tumour_RT_death_rate = detail::getR(P, "tumour/RT_death_rate"); p.tumour_RT_exp_a = detail::getR(P, "tumour/RT_exp_a");
+  p.tumour_RT_exp_b = detail::getR(P, "tumour/RT_exp_b"); p.tumour_necrosis_rate = detail::getR(P, "tumour/necrosis_rate");
+  p.necrosis_clearance = detail::getR(P, "necrosis/clearance"); p.necrosis_slope = detail::getR(P, "necrosis/slope");
+  p.necrosis_vsc_threshold = detail::getR(P, "necrosis/vsc_threshold");
+  p.vascular_proliferation = detail::getR(P, "vascular/proliferation"); p.vascular_necrosis_rate = detail::getR(P, "vascular/necrosis_rate");
+  p.oedema_diffusion = detail::getR(P, "oedema/diffusion"); p.oedema_proliferation = detail::getR(P, "oedema/proliferation");
+  p.oedema_vsc_threshold = detail::getR(P, "oedema/vsc_threshold"); p.oedema_RT_coeff = detail::getR(P, "oedema/RT_coeff");
+  p.oedema_RT_exp = detail::getR(P, "oedema/RT_exp"); p.oedema_reabsorption_rate = detail::getR(P, "oedema/reabsorption_rate");
+  const int64_t nn = es.get_mesh().n_nodes();
+  std::vector<double> aux((size_t)nn * 3, 0.0);
+  for (int64_t n = 0; n < nn; n++) {
+    aux[(size_t)n * 3 + 0] = AUX.current_solution((dof_id_type)(n * 2 + 0));  // "HU": the only AUX variable the assembly reads (:472,481)
+    aux[(size_t)n * 3 + 1] = AUX.current_solution((dof_id_type)(n * 2 + 1));  // "RTD"
+  }
+  rdc_ctx* c = es.context(system_name, 5);
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.old_local_solution.raw().data(), system.old_local_solution.size()), "old solution");
+  check(c, rdc_field_upload(c, RDC_FIELD_AUX_NODAL, aux.data(), (int64_t)aux.size()), "aux fields");
+  check(c, rdc_assemble_proteas(c, &p), "rdc_assemble_proteas");
+  detail::pull_results(c, system);
+}
+
+// check_solution of PIHNA / HCC / ADPM-style models: negativity clamp of the freshly solved state
+// (src/pihna.C:760-803, src/coupled_hcc.C:695-731, src/proteas.C:712-750), on the device
+inline void check_solution(EquationSystems& es, const std::string& system_name) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  rdc_ctx* c = es.context(system_name, (int)system.n_vars());
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.solution.raw().data(), system.solution.size()), "solution");
+  check(c, rdc_clamp_nonnegative(c, RDC_FIELD_OLD_SOLUTION), "rdc_clamp_nonnegative");
+  check(c, rdc_field_download(c, RDC_FIELD_OLD_SOLUTION, system.solution.raw().data(), system.solution.size()), "solution");
+  system.update();
 }
 
 }  // namespace host

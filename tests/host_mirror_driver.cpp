@@ -27,7 +27,7 @@ template <class T> void write_raw(const std::string& f, const std::vector<T>& v)
 }
 
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: driver <dir> <model: pihna|ripf|hcc> <elem_type> [solve]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: driver <dir> <model: pihna|ripf|hcc|adpm|proteas> <elem_type> [solve]\n"); return 2; }
   const std::string dir = argv[1], model_name = argv[2];
   const int elem_type = std::atoi(argv[3]);
   const bool do_solve = argc > 4 && std::string(argv[4]) == "solve";
@@ -59,6 +59,19 @@ int main(int argc, char** argv) {
       model = &es.add_system<TransientLinearImplicitSystem>("HCC");
       for (const char* v : {"l", "c", "n"}) model->add_variable(v);
       model->attach_assemble_function(assemble_hcc);
+    } else if (model_name == "adpm") {
+      model = &es.add_system<TransientLinearImplicitSystem>("ADPM");
+      for (const char* v : {"PrP", "A_b", "Tau"}) model->add_variable(v);
+      model->attach_assemble_function(assemble_adpm);
+      System& tr = es.add_system<System>("Tracts");
+      tr.elemental = true;
+      for (const char* v : {"tract_x", "tract_y", "tract_z"}) tr.add_variable(v);
+    } else if (model_name == "proteas") {
+      model = &es.add_system<TransientLinearImplicitSystem>("PROTEAS_model");
+      for (const char* v : {"hos", "tum", "nec", "vsc", "oed"}) model->add_variable(v);
+      model->attach_assemble_function(assemble_proteas_model);
+      System& aux = es.add_system<System>("AUX");
+      for (const char* v : {"HU", "RTD"}) aux.add_variable(v);
     } else {
       throw std::runtime_error("unknown model " + model_name);
     }
@@ -69,6 +82,11 @@ int main(int argc, char** argv) {
       es.get_system<System>("RIPF-TimeDeriv").current_local_solution.raw() = read_raw<double>(dir + "/td.bin");
       es.get_system<System>("RT").current_local_solution.raw() = read_raw<double>(dir + "/rt.bin");
     }
+    if (model_name == "adpm") {
+      es.get_system<System>("Tracts").solution.raw() = read_raw<double>(dir + "/tracts.bin");
+      model->time = es.parameters.get<Real>("time");
+    }
+    if (model_name == "proteas") es.get_system<System>("AUX").current_local_solution.raw() = read_raw<double>(dir + "/aux2.bin");
     // the time-loop prologue, src/pihna.C:77-78
     model->older_local_solution = model->old_local_solution;
     model->old_local_solution = model->current_local_solution;
@@ -82,6 +100,15 @@ int main(int argc, char** argv) {
       write_raw(dir + "/solution.bin", model->solution.raw());
     } else {
       model->assemble();
+    }
+    {  // check_solution(): the clamp of the solved state runs on the device through the same context
+      std::vector<double> keep = model->solution.raw();
+      for (size_t i = 0; i < model->solution.raw().size(); i += 7) model->solution.raw()[i] = -1.0 - (double)i;
+      std::vector<double> expect = model->solution.raw();
+      for (double& x : expect) if (x < 0.0) x = 0.0;
+      check_solution(es, model->name());
+      if (model->solution.raw() != expect) throw std::runtime_error("check_solution: clamp mismatch");
+      model->solution.raw() = keep;
     }
     write_raw(dir + "/val.bin", model->matrix->val);
     write_raw(dir + "/rhs.bin", model->rhs->raw());
