@@ -50,14 +50,43 @@ template <> struct Ref<8> {
       dN[n][2] = 0.125 * a * b * sz(n);
     }
   }
+  // the same values at the 8 Gauss points as compile-time data: with the quadrature loop kept rolled the point index is
+  // wave-uniform, so these become scalar loads / scalar operands instead of ~100 FP64 operations and 64 VGPRs per point
+  struct Tab { double N[8][8], dN[8][8][3]; };
+  static constexpr Tab make_tab() {
+    Tab t{};
+    const double g = 0.57735026918962576451;
+    for (int q = 0; q < 8; q++) {
+      const double x = (q & 1) ? g : -g, y = (q & 2) ? g : -g, z = (q & 4) ? g : -g;
+      for (int n = 0; n < 8; n++) {
+        const double s0 = ((n & 3) == 1 || (n & 3) == 2) ? 1.0 : -1.0, s1 = ((n & 3) >= 2) ? 1.0 : -1.0, s2 = (n >= 4) ? 1.0 : -1.0;
+        const double a = 1.0 + s0 * x, b = 1.0 + s1 * y, c = 1.0 + s2 * z;
+        t.N[q][n] = 0.125 * a * b * c;
+        t.dN[q][n][0] = 0.125 * s0 * b * c;
+        t.dN[q][n][1] = 0.125 * a * s1 * c;
+        t.dN[q][n][2] = 0.125 * a * b * s2;
+      }
+    }
+    return t;
+  }
 };
+static constexpr Ref<8>::Tab kHex8Tab = Ref<8>::make_tab();
+__attribute__((unused)) static const void* const kHex8TabRef = &kHex8Tab;
 
 // physical shape data at one quadrature point: phi, grad phi, JxW = det(J) * w
 template <int NEN>
 RDC_HD void fe_point(const double (&X)[NEN][3], int q, double (&N)[NEN], double (&G)[NEN][3], double& JxW) {
   double xi[3], w, dN[NEN][3];
   Ref<NEN>::qpoint(q, xi, w);
-  Ref<NEN>::shape(xi, N, dN);
+  if constexpr (NEN == 8) {
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      N[n] = kHex8Tab.N[q][n];
+      dN[n][0] = kHex8Tab.dN[q][n][0]; dN[n][1] = kHex8Tab.dN[q][n][1]; dN[n][2] = kHex8Tab.dN[q][n][2];
+    }
+  } else {
+    Ref<NEN>::shape(xi, N, dN);
+  }
   double J[3][3];
 #pragma unroll
   for (int r = 0; r < 3; r++)
