@@ -45,6 +45,8 @@ struct rdc_ctx {
   DevBuf val, rhs, packed;
   DevBuf stamps;
   DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab, rg4_nlist, rg4_ploc;
+  DevBuf hx_nl_ptr, hx_nlist, hx_ploc;   // node-staged generic row gather (HEX8)
+  int opt_staged = 1;
   DevBuf rg5_eid;             // pair -> element list, uploaded at the first assembly of a model with per-element inputs
   bool rg5_eid_ready = false;
   DevBuf field[RDC_FIELD_COUNT];
@@ -217,6 +219,13 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.u = (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p;
   a.aux = (const double*)c->field[RDC_FIELD_AUX_NODAL].p;
   a.elem = (const double*)c->field[RDC_FIELD_ELEM_TRACTS].p;
+  if (c->prep.hx_ok) {
+    a.hx_nl_ptr = (const int64_t*)c->hx_nl_ptr.p;
+    a.hx_nlist = (const uint32_t*)c->hx_nlist.p;
+    a.hx_ploc = (const uint16_t*)c->hx_ploc.p;
+    a.hx_max_nodes = c->prep.hx_max_nodes;
+  }
+  a.opt_staged = c->opt_staged;
   a.packed = (double*)c->packed.p;
   a.variant = c->variant;
   a.opt_occ = c->opt_occ;
@@ -309,7 +318,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
-                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg5_eid,
+                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
                    &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post};
   for (DevBuf* b : all) dev_free(c, *b);
@@ -358,6 +367,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   }
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
   else if (!std::strcmp(key, "slim")) c->opt_slim = value;
+  else if (!std::strcmp(key, "staged")) c->opt_staged = value;  // HEX8 generic row gather: node table in LDS (default 1)
   else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
   else if (!std::strcmp(key, "grid")) c->opt_grid = value;
@@ -408,6 +418,11 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   if ((rc = dev_upload(c, c->pair_local, P.pair_local))) return rc;
   if ((rc = dev_upload(c, c->node_pair_ptr, P.node_pair_ptr))) return rc;
   if ((rc = dev_upload(c, c->wg_node_ptr, P.wg_node_ptr))) return rc;
+  if (P.hx_ok) {
+    if ((rc = dev_upload(c, c->hx_nl_ptr, P.hx_nl_ptr))) return rc;
+    if ((rc = dev_upload(c, c->hx_nlist, P.hx_nlist))) return rc;
+    if ((rc = dev_upload(c, c->hx_ploc, P.hx_ploc))) return rc;
+  }
   if (P.rg2_ok && elem_type == RDC_TET4) {
     if ((rc = dev_upload(c, c->rg2_desc, P.wg2))) return rc;
     if ((rc = dev_upload(c, c->rg2_pair, P.pair_rec))) return rc;

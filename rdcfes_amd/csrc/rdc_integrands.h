@@ -105,6 +105,7 @@ struct PihnaK {  // src/pihna.C:358-381
 };
 
 struct Pihna {
+  static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 0;  // per-element input doubles
   RDC_HD static void grad_post(const PihnaK&, double (*)[3], const double*) {}
@@ -313,6 +314,7 @@ struct RipfK {
 };
 
 struct Ripf {
+  static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 0;  // per-element input doubles
   RDC_HD static void grad_post(const RipfK&, double (*)[3], const double*) {}
@@ -457,6 +459,7 @@ struct HccK {
 };
 
 struct Hcc {
+  static constexpr bool HEX_STAGED = true;   // node-staged HEX8 row gather: 1.70 -> 1.43 ms on H(80) (tools/hex_ab.py)
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 0;  // per-element input doubles
   RDC_HD static void grad_post(const HccK&, double (*)[3], const double*) {}
@@ -578,6 +581,7 @@ struct AdpmK {
 };
 
 struct Adpm {
+  static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
   static constexpr int NELEM = 3;   // tract vector of the element
   static constexpr int NV = 3, NG = 4, NAUX = 0;
@@ -704,6 +708,7 @@ struct ProteasK {
 };
 
 struct Proteas {
+  static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr int AUX_LOCAL_NODE = 1;
   static constexpr int NELEM = 0;
   RDC_HD static void grad_post(const ProteasK&, double (*)[3], const double*) {}

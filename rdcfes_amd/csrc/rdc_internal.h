@@ -37,6 +37,12 @@ struct LaunchArgs {
   int nen, exp_mode, strategy;
   const double* u;
   const double* aux;
+  // node-staged generic row gather (HEX8)
+  const int64_t* hx_nl_ptr = nullptr;
+  const uint32_t* hx_nlist = nullptr;
+  const uint16_t* hx_ploc = nullptr;
+  int hx_max_nodes = 0;
+  int opt_staged = 1;
   const double* elem = nullptr;  // per-element inputs ([n_elem][M::NELEM]) of models that have them (ADPM tracts)
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "rdc_row.h"
 
 namespace rdc {
@@ -102,6 +103,40 @@ k_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t count,
   }
 }
 
+// one equation row A of a (node, element) pair over all quadrature points, added into the LDS row slice
+template <class M, int NEN, int EXP_MODE, int A>
+__device__ __forceinline__ void rowsplit_row(const MeshDev& m, const typename M::K& k, const double (&X)[NEN][3],
+                                             const double (&U)[NEN][M::NV], const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1],
+                                             int64_t e, int i, const double* ED, double* row, int len, double* lrhs) {
+  constexpr int NV = M::NV;
+  double acc[NV][NEN], fe = 0.0;
+#pragma unroll
+  for (int b = 0; b < NV; b++)
+#pragma unroll
+    for (int j = 0; j < NEN; j++) acc[b][j] = 0.0;
+#pragma unroll 1
+  for (int q = 0; q < Ref<NEN>::NQP; q++) {
+    RowPoint<M, NEN> P;
+    rd_point_setup<M, NEN, EXP_MODE>(k, X, U, AX, q, i, ED, P);
+    rd_point_accum_row<M, NEN, A>(P, acc, fe);
+  }
+#pragma unroll
+  for (int j = 0; j < NEN; j++) {
+    const int s = m.eslot[e * (NEN * NEN) + i * NEN + j];
+#pragma unroll
+    for (int b = 0; b < NV; b++)
+      __hip_atomic_fetch_add(row + A * NV * len + NV * s + b, acc[b][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __hip_atomic_fetch_add(lrhs + A, fe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class M, int NEN, int EXP_MODE, int... As>
+__device__ __forceinline__ void rowsplit_rows(std::integer_sequence<int, As...>, const MeshDev& m, const typename M::K& k,
+                                              const double (&X)[NEN][3], const double (&U)[NEN][M::NV],
+                                              const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int64_t e, int i,
+                                              const double* ED, double* row, int len, double* lrhs) {
+  (rowsplit_row<M, NEN, EXP_MODE, As>(m, k, X, U, AX, e, i, ED, row, len, lrhs), ...);
+}
+
 // ---- row gather ---------------------------------------------------------------------------
 // One workgroup owns the consecutive owned nodes [wg_node_ptr[w], wg_node_ptr[w+1]); their CSR
 // rows form ONE contiguous slice of val[].  One thread per (node, incident element) pair
@@ -136,8 +171,113 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
     uint32_t nd[NEN];
     double X[NEN][3], U[NEN][NV], AX[NEN][M::NAUX > 0 ? M::NAUX : 1];
     load_element<M, NEN>(m, e, u, aux, nd, X, U, AX);
+    const double* ED = M::NELEM > 0 ? elem + e * M::NELEM : nullptr;
+    const int64_t I = m.conn[e * NEN + i];
+    const int64_t b0 = m.bptr[I];
+    const int len = (int)(m.bptr[I + 1] - b0);
+    double* row = lds + ((int64_t)NV * NV * b0 - vb0);
+    if constexpr (NV * NV * NEN > 128) {
+      // The full NV x NV x NEN accumulator (200 doubles for five unknowns on HEX8) does not fit the register file
+      // (hundreds of bytes of scratch per lane, 39 ms for 0.5 M hexes): one equation row at a time instead -- the
+      // per-point set-up is redone NV times, everything stays in registers.
+      rowsplit_rows<M, NEN, EXP_MODE>(std::make_integer_sequence<int, NV>{}, m, k, X, U, AX, e, i, ED, row, len,
+                                      lrhs + (I - n0) * NV);
+      continue;
+    }
     double acc[NV][NV][NEN], fe[NV];
-    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe, M::NELEM > 0 ? elem + e * M::NELEM : nullptr);
+    rd_row<M, NEN, EXP_MODE>(k, X, U, AX, i, acc, fe, ED);
+#pragma unroll
+    for (int j = 0; j < NEN; j++) {
+      const int s = m.eslot[e * (NEN * NEN) + i * NEN + j];
+#pragma unroll
+      for (int a = 0; a < NV; a++)
+#pragma unroll
+        for (int b = 0; b < NV; b++)
+          __hip_atomic_fetch_add(row + a * NV * len + NV * s + b, acc[a][b][j], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int a = 0; a < NV; a++)
+      __hip_atomic_fetch_add(lrhs + (I - n0) * NV + a, fe[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  double* out = val + vb0;
+  for (int x = threadIdx.x; x < nval; x += BLOCK) out[x] = lds[x];
+  double* orhs = rhs + n0 * NV;
+  for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
+}
+
+// ---- node-staged row gather (HEX8) ------------------------------------------------------------------
+// Same decomposition as k_rowgather, but the coordinates / unknowns / aux values of the workgroup's distinct
+// nodes are first copied into LDS ([node][3 + NV + NAUX] doubles) and every quadrature point re-reads the eight
+// nodes of its element from there instead of holding them in registers for the whole loop (96 VGPRs on HEX8 with
+// three unknowns): the generic evaluator then fits two waves per SIMD.
+template <class M, int NEN, int EXP_MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
+k_rowgather_staged(const MeshDev m, const typename M::K k, const double* __restrict__ u, const double* __restrict__ aux,
+                   const double* __restrict__ elem, const int64_t* __restrict__ nl_ptr, const uint32_t* __restrict__ nlist,
+                   const uint16_t* __restrict__ ploc, const int tab_off, double* __restrict__ val,
+                   double* __restrict__ rhs) {
+  constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1), REC = 3 + NV + (M::NAUX > 0 ? M::NAUX : 0);
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int w = blockIdx.x;
+  const int64_t n0 = m.wg_node_ptr[w], n1 = m.wg_node_ptr[w + 1];
+  const int64_t vb0 = (int64_t)NV * NV * m.bptr[n0];
+  const int nval = (int)((int64_t)NV * NV * m.bptr[n1] - vb0);
+  const int nrhs = (int)(n1 - n0) * NV;
+  double* lrhs = lds + nval;
+  double* tab = lds + tab_off;
+  for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
+  {
+    const int64_t l0 = nl_ptr[w];
+    const int nn = (int)(nl_ptr[w + 1] - l0);
+    for (int x = threadIdx.x; x < nn; x += BLOCK) {
+      const int64_t n = nlist[l0 + x];
+      double* r = tab + x * REC;
+      r[0] = m.xyz[3 * n]; r[1] = m.xyz[3 * n + 1]; r[2] = m.xyz[3 * n + 2];
+#pragma unroll
+      for (int v = 0; v < NV; v++) r[3 + v] = u[n * NV + v];
+      if (M::NAUX > 0) {
+#pragma unroll
+        for (int v = 0; v < M::NAUX; v++) r[3 + NV + v] = aux[n * M::NAUX + v];
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t p0 = m.node_pair_ptr[n0], p1 = m.node_pair_ptr[n1];
+  constexpr int GRP = BLOCK / 8;
+  const int64_t tperm = (int64_t)(threadIdx.x % GRP) * 8 + threadIdx.x / GRP;  // see k_rowgather
+  for (int64_t p = p0 + tperm; p < p1; p += BLOCK) {
+    const int64_t e = m.pair_elem[p];
+    const int i = m.pair_local[p];
+    int li[NEN];
+    {
+      const uint4 a0 = reinterpret_cast<const uint4*>(ploc)[p * NEN / 8];
+      li[0] = a0.x & 0xFFFF; li[1] = a0.x >> 16; li[2] = a0.y & 0xFFFF; li[3] = a0.y >> 16;
+      if (NEN == 8) { li[4 % NEN] = a0.z & 0xFFFF; li[5 % NEN] = a0.z >> 16; li[6 % NEN] = a0.w & 0xFFFF; li[7 % NEN] = a0.w >> 16; }
+    }
+    double acc[NV][NV][NEN], fe[NV];
+    rd_row_zero<M, NEN>(acc, fe);
+#pragma unroll 1
+    for (int q = 0; q < Ref<NEN>::NQP; q++) {
+      int off = 0;
+      asm volatile("" : "+v"(off));  // opaque per iteration: keeps the node reads inside the loop (not hoisted back into registers)
+      double X[NEN][3], U[NEN][NV], AX[NEN][NA];
+#pragma unroll
+      for (int l = 0; l < NEN; l++) {
+        const double* r = tab + (li[l] * REC + off);
+        X[l][0] = r[0]; X[l][1] = r[1]; X[l][2] = r[2];
+#pragma unroll
+        for (int v = 0; v < NV; v++) U[l][v] = r[3 + v];
+        if (M::NAUX > 0) {
+#pragma unroll
+          for (int v = 0; v < M::NAUX; v++) AX[l][v] = (M::AUX_LOCAL_NODE < 0 || l == M::AUX_LOCAL_NODE) ? r[3 + NV + v] : 0.0;
+        } else {
+          AX[l][0] = 0.0;
+        }
+      }
+      rd_row_point<M, NEN, EXP_MODE>(k, X, U, AX, q, i, acc, fe, M::NELEM > 0 ? elem + e * M::NELEM : nullptr);
+    }
     const int64_t I = m.conn[e * NEN + i];
     const int64_t b0 = m.bptr[I];
     const int len = (int)(m.bptr[I + 1] - b0);

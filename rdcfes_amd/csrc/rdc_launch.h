@@ -11,9 +11,28 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
   if (a.strategy == RDC_SCATTER_ROWGATHER) {
     constexpr int BLOCK = 256;
-    if (a.n_wg > 0)
+    if (a.n_wg > 0) {
+      if constexpr (NEN == 8) {
+        // node-staged form when the workgroup's row slice and node table fit 80 KB of LDS (two workgroups per CU)
+        constexpr int REC = 3 + M::NV + (M::NAUX > 0 ? M::NAUX : 0);
+        const size_t tab_off = (a.lds_bytes / sizeof(double) + 1) & ~(size_t)1;
+        const size_t staged_bytes = sizeof(double) * (tab_off + (size_t)a.hx_max_nodes * REC);
+        // opt_staged: 1 = where the model profits (M::HEX_STAGED), 2 = always, 0 = never
+        if ((a.opt_staged == 2 || (a.opt_staged == 1 && M::HEX_STAGED)) && a.hx_ploc && staged_bytes <= 80 * 1024) {
+          static bool attr_set = false;  // per instantiation
+          if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_rowgather_staged<M, NEN, EXP_MODE, BLOCK>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            attr_set = true;
+          }
+          hipLaunchKernelGGL((k_rowgather_staged<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), staged_bytes, a.stream,
+                             a.m, k, a.u, a.aux, a.elem, a.hx_nl_ptr, a.hx_nlist, a.hx_ploc, (int)tab_off, a.val, a.rhs);
+          return hipGetLastError();
+        }
+      }
       hipLaunchKernelGGL((k_rowgather<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), a.lds_bytes,
                          a.stream, a.m, k, a.u, a.aux, a.elem, a.val, a.rhs);
+    }
     return hipGetLastError();
   }
   // coloured: one launch per colour, stream order is the only synchronisation needed

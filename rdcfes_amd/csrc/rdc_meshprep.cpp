@@ -190,6 +190,43 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
     P.wg_node_ptr.push_back((int32_t)n_owned);
     P.rg_lds_bytes = max_bytes;
     if (!P.rowgather_ok) { P.wg_node_ptr.assign(2, 0); P.wg_node_ptr[1] = 0; }
+    // node lists of the workgroups for the node-staged kernel (HEX8 only: TET4 has its own factored path)
+    P.hx_ok = false;
+    P.hx_nl_ptr.clear(); P.hx_nlist.clear(); P.hx_ploc.clear(); P.hx_max_nodes = 0;
+    if (P.rowgather_ok && nen == 8) {
+      const int64_t nwg = (int64_t)P.wg_node_ptr.size() - 1;
+      std::vector<std::vector<uint32_t>> lists((size_t)nwg);
+      P.hx_ploc.assign((size_t)npairs * nen, 0);
+      int bad = 0;
+#pragma omp parallel for schedule(dynamic, 64)
+      for (int64_t w = 0; w < nwg; w++) {
+        const int64_t p0 = P.node_pair_ptr[P.wg_node_ptr[w]], p1 = P.node_pair_ptr[P.wg_node_ptr[w + 1]];
+        std::vector<uint32_t>& l = lists[(size_t)w];
+        l.reserve((size_t)(p1 - p0) * nen);
+        for (int64_t p = p0; p < p1; p++)
+          for (int j = 0; j < nen; j++) l.push_back(conn[(int64_t)P.pair_elem[p] * nen + j]);
+        std::sort(l.begin(), l.end());
+        l.erase(std::unique(l.begin(), l.end()), l.end());
+        if (l.size() > 0xFFFF) { bad = 1; continue; }
+        for (int64_t p = p0; p < p1; p++)
+          for (int j = 0; j < nen; j++)
+            P.hx_ploc[(size_t)p * nen + j] =
+                (uint16_t)(std::lower_bound(l.begin(), l.end(), conn[(int64_t)P.pair_elem[p] * nen + j]) - l.begin());
+      }
+      if (!bad) {
+        P.hx_nl_ptr.assign((size_t)nwg + 1, 0);
+        for (int64_t w = 0; w < nwg; w++) {
+          P.hx_nl_ptr[(size_t)w + 1] = P.hx_nl_ptr[(size_t)w] + (int64_t)lists[(size_t)w].size();
+          P.hx_max_nodes = std::max(P.hx_max_nodes, (int)lists[(size_t)w].size());
+        }
+        P.hx_nlist.resize((size_t)P.hx_nl_ptr[(size_t)nwg]);
+        for (int64_t w = 0; w < nwg; w++)
+          std::copy(lists[(size_t)w].begin(), lists[(size_t)w].end(), P.hx_nlist.begin() + P.hx_nl_ptr[(size_t)w]);
+        P.hx_ok = true;
+      } else {
+        P.hx_ploc.clear();
+      }
+    }
   }
 
   // ---- staged row gather: workgroups of <= block pairs, flat descriptors, balanced chunks ------

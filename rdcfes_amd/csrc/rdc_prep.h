@@ -32,6 +32,13 @@ struct HostPrep {
   std::vector<uint8_t> pair_local;
   std::vector<int64_t> node_pair_ptr;
   std::vector<int32_t> wg_node_ptr;
+  // node-staged generic row gather (HEX8): the distinct nodes of a workgroup's pairs, so their coordinates and
+  // unknowns can sit in LDS instead of 96 registers per lane; pairs address them by 16-bit list positions
+  bool hx_ok = false;
+  std::vector<int64_t> hx_nl_ptr;     // [n_wg + 1] into hx_nlist
+  std::vector<uint32_t> hx_nlist;     // node ids
+  std::vector<uint16_t> hx_ploc;      // [n_pairs][nen] list position of the pair's element nodes (local order)
+  int hx_max_nodes = 0;               // largest list
   // staged row gather ("rg2"): flat per-workgroup descriptors so the kernel needs only two
   // dependent load levels, and balanced contribution chunks for the deterministic LDS gather
   struct WgDesc {          // 64 bytes

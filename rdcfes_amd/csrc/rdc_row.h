@@ -8,6 +8,131 @@
 
 namespace rdc {
 
+template <class M, int NEN>
+RDC_HD void rd_row_zero(double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV]) {
+#pragma unroll
+  for (int a = 0; a < M::NV; a++) {
+    fe[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < M::NV; b++)
+#pragma unroll
+      for (int j = 0; j < NEN; j++) acc[a][b][j] = 0.0;
+  }
+}
+
+// ---- everything a quadrature point contributes to the row of local node `irow`, before the accumulation -------
+template <class M, int NEN>
+struct RowPoint {
+  double N[NEN], G[NEN][3], W, Ni, Gi[3], gi[M::NG];
+  typename M::C c;
+};
+
+template <class M, int NEN, int EXP_MODE>
+RDC_HD void rd_point_setup(const typename M::K& k, const double (&X)[NEN][3], const double (&U)[NEN][M::NV],
+                           const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int q, int irow, const double* ED,
+                           RowPoint<M, NEN>& P) {
+  constexpr int NV = M::NV, NG = M::NG, NA = (M::NAUX > 0 ? M::NAUX : 1);
+  fe_point<NEN>(X, q, P.N, P.G, P.W);
+  // old solution, aux fields and gradient fields at the point (src/pihna.C:429-442)
+  double uq[NV], aq[NA], GF[NG][3];
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < NEN; l++) s += P.N[l] * U[l][v];
+    uq[v] = s;
+  }
+#pragma unroll
+  for (int v = 0; v < NA; v++) {
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < NEN; l++) s += P.N[l] * AX[l][v];
+    aq[v] = s;
+  }
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    const int src = M::grad_src(g);
+    if (src >= NV) { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; continue; }  // filled by grad_post()
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l < NEN; l++) s += P.G[l][d] * (src >= 0 ? U[l][(src >= 0 && src < NV) ? src : 0] : AX[l][src < 0 ? (-1 - src) % NA : 0]);
+      GF[g][d] = s;
+    }
+    if (src < 0) {  // RIPF: unit radiotherapy gradient (src/ripf.C:481-484)
+      const double l2 = sqrt(GF[g][0] * GF[g][0] + GF[g][1] * GF[g][1] + GF[g][2] * GF[g][2]);
+      if (l2 != 0.0) { GF[g][0] /= l2; GF[g][1] /= l2; GF[g][2] /= l2; }
+      else { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; }
+    }
+  }
+  if (M::NELEM > 0) M::grad_post(k, GF, ED);
+  typename M::Pt pt;
+  M::template point<EXP_MODE>(k, uq, aq, pt);
+  M::coef(k, pt, P.c);
+  // shape data of the row node
+  P.Ni = 0.0; P.Gi[0] = 0.0; P.Gi[1] = 0.0; P.Gi[2] = 0.0;
+#pragma unroll
+  for (int n = 0; n < NEN; n++)
+    if (n == irow) { P.Ni = P.N[n]; P.Gi[0] = P.G[n][0]; P.Gi[1] = P.G[n][1]; P.Gi[2] = P.G[n][2]; }
+#pragma unroll
+  for (int g = 0; g < NG; g++) P.gi[g] = GF[g][0] * P.Gi[0] + GF[g][1] * P.Gi[1] + GF[g][2] * P.Gi[2];
+}
+
+// equation row A only (everything else of coef() is dead code): for element types / models whose full NV x NV x NEN
+// accumulator does not fit the register file
+template <class M, int NEN, int A>
+RDC_HD void rd_point_accum_row(const RowPoint<M, NEN>& P, double (&acc)[M::NV][NEN], double& fe) {
+  constexpr int NV = M::NV, NG = M::NG;
+  double r = P.c.R[A] * P.Ni;
+#pragma unroll
+  for (int g = 0; g < NG; g++) r += P.c.RG[A][g] * P.gi[g];
+  fe += P.W * r;
+#pragma unroll
+  for (int j = 0; j < NEN; j++) {
+    const double pp = P.N[j] * P.Ni;
+    const double dd = P.G[j][0] * P.Gi[0] + P.G[j][1] * P.Gi[1] + P.G[j][2] * P.Gi[2];
+#pragma unroll
+    for (int b = 0; b < NV; b++) {
+      double bg = 0.0;
+#pragma unroll
+      for (int g = 0; g < NG; g++) bg += P.c.B[A][b][g] * P.gi[g];
+      acc[b][j] += P.W * (P.c.A[A][b] * pp + P.N[j] * bg + P.c.D[A][b] * dd);
+    }
+  }
+}
+
+// ---- contribution of quadrature point q to the row of local node `irow` ------------------------------
+template <class M, int NEN, int EXP_MODE>
+RDC_HD void rd_row_point(const typename M::K& k, const double (&X)[NEN][3], const double (&U)[NEN][M::NV],
+                         const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int q, int irow,
+                         double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV], const double* ED) {
+  constexpr int NV = M::NV, NG = M::NG;
+  RowPoint<M, NEN> P;
+  rd_point_setup<M, NEN, EXP_MODE>(k, X, U, AX, q, irow, ED, P);
+#pragma unroll
+  for (int a = 0; a < NV; a++) {
+    double r = P.c.R[a] * P.Ni;
+#pragma unroll
+    for (int g = 0; g < NG; g++) r += P.c.RG[a][g] * P.gi[g];
+    fe[a] += P.W * r;
+  }
+#pragma unroll
+  for (int j = 0; j < NEN; j++) {
+    const double pp = P.N[j] * P.Ni;
+    const double dd = P.G[j][0] * P.Gi[0] + P.G[j][1] * P.Gi[1] + P.G[j][2] * P.Gi[2];
+#pragma unroll
+    for (int a = 0; a < NV; a++)
+#pragma unroll
+      for (int b = 0; b < NV; b++) {
+        double bg = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) bg += P.c.B[a][b][g] * P.gi[g];
+        acc[a][b][j] += P.W * (P.c.A[a][b] * pp + P.N[j] * bg + P.c.D[a][b] * dd);
+      }
+  }
+}
+
 // ---- one row (local node `irow`) of Ke and Fe over all quadrature points ------------------
 template <class M, int NEN, int EXP_MODE>
 RDC_HD void rd_row(const typename M::K& k, const double (&X)[NEN][3],
@@ -15,87 +140,9 @@ RDC_HD void rd_row(const typename M::K& k, const double (&X)[NEN][3],
                                        const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int irow,
                                        double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV],
                                        const double* ED = nullptr /* M::NELEM per-element inputs */) {
-  constexpr int NV = M::NV, NG = M::NG, NA = (M::NAUX > 0 ? M::NAUX : 1);
-#pragma unroll
-  for (int a = 0; a < NV; a++) {
-    fe[a] = 0.0;
-#pragma unroll
-    for (int b = 0; b < NV; b++)
-#pragma unroll
-      for (int j = 0; j < NEN; j++) acc[a][b][j] = 0.0;
-  }
+  rd_row_zero<M, NEN>(acc, fe);
 #pragma unroll 1
-  for (int q = 0; q < Ref<NEN>::NQP; q++) {
-    double N[NEN], G[NEN][3], W;
-    fe_point<NEN>(X, q, N, G, W);
-    // old solution, aux fields and gradient fields at the point (src/pihna.C:429-442)
-    double uq[NV], aq[NA], GF[NG][3];
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      double s = 0.0;
-#pragma unroll
-      for (int l = 0; l < NEN; l++) s += N[l] * U[l][v];
-      uq[v] = s;
-    }
-#pragma unroll
-    for (int v = 0; v < NA; v++) {
-      double s = 0.0;
-#pragma unroll
-      for (int l = 0; l < NEN; l++) s += N[l] * AX[l][v];
-      aq[v] = s;
-    }
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      const int src = M::grad_src(g);
-      if (src >= NV) { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; continue; }  // filled by grad_post()
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        double s = 0.0;
-#pragma unroll
-        for (int l = 0; l < NEN; l++) s += G[l][d] * (src >= 0 ? U[l][(src >= 0 && src < NV) ? src : 0] : AX[l][src < 0 ? (-1 - src) % NA : 0]);
-        GF[g][d] = s;
-      }
-      if (src < 0) {  // RIPF: unit radiotherapy gradient (src/ripf.C:481-484)
-        const double l2 = sqrt(GF[g][0] * GF[g][0] + GF[g][1] * GF[g][1] + GF[g][2] * GF[g][2]);
-        if (l2 != 0.0) { GF[g][0] /= l2; GF[g][1] /= l2; GF[g][2] /= l2; }
-        else { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; }
-      }
-    }
-    if (M::NELEM > 0) M::grad_post(k, GF, ED);
-    typename M::Pt pt;
-    M::template point<EXP_MODE>(k, uq, aq, pt);
-    typename M::C c;
-    M::coef(k, pt, c);
-    // shape data of the row node
-    double Ni = 0.0, Gi[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int n = 0; n < NEN; n++)
-      if (n == irow) { Ni = N[n]; Gi[0] = G[n][0]; Gi[1] = G[n][1]; Gi[2] = G[n][2]; }
-    double gi[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) gi[g] = GF[g][0] * Gi[0] + GF[g][1] * Gi[1] + GF[g][2] * Gi[2];
-#pragma unroll
-    for (int a = 0; a < NV; a++) {
-      double r = c.R[a] * Ni;
-#pragma unroll
-      for (int g = 0; g < NG; g++) r += c.RG[a][g] * gi[g];
-      fe[a] += W * r;
-    }
-#pragma unroll
-    for (int j = 0; j < NEN; j++) {
-      const double pp = N[j] * Ni;
-      const double dd = G[j][0] * Gi[0] + G[j][1] * Gi[1] + G[j][2] * Gi[2];
-#pragma unroll
-      for (int a = 0; a < NV; a++)
-#pragma unroll
-        for (int b = 0; b < NV; b++) {
-          double bg = 0.0;
-#pragma unroll
-          for (int g = 0; g < NG; g++) bg += c.B[a][b][g] * gi[g];
-          acc[a][b][j] += W * (c.A[a][b] * pp + N[j] * bg + c.D[a][b] * dd);
-        }
-    }
-  }
+  for (int q = 0; q < Ref<NEN>::NQP; q++) rd_row_point<M, NEN, EXP_MODE>(k, X, U, AX, q, irow, acc, fe, ED);
 }
 
 }  // namespace rdc
