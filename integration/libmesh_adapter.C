@@ -144,9 +144,74 @@ void assemble_pihna(EquationSystems& es, const std::string& system_name) {
   push_results(es, system, B, 5);
 }
 
-// assemble_ripf / assemble_hcc follow the same pattern (parameter keys: src/ripf.C:377-408,
-// src/coupled_hcc.C:450-461; RIPF additionally gathers TD vars 1,2 and RT var 2 into
-// RDC_FIELD_AUX_NODAL; HCC calls rdc_mesh_update_coords with the current node positions first).
-// See rdcfes_amd/host/rdc_host.h::assemble_ripf / assemble_hcc for the exact call sequences.
+// src/coupled_hcc.C:414-649.  The mesh is the CURRENT configuration (SolidSystem::update moved the nodes,
+// src/coupled_hcc.C:98-114), so the coordinates are refreshed before every assembly.
+void assemble_hcc(EquationSystems& es, const std::string& system_name) {
+  TransientLinearImplicitSystem& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  libmesh_assert_equal_to(system.n_vars(), 3);
+  Binding& B = bind(es, system_name, 3);
+  rdc_hcc_params p;   // src/coupled_hcc.C:450-461
+  p.time_step = es.parameters.get<Real>("time_step");
+  p.cells_min_capacity = es.parameters.get<Real>("cells/min_capacity");
+  p.cells_max_capacity = es.parameters.get<Real>("cells/max_capacity");
+  p.cells_max_capacity_exponent = es.parameters.get<Real>("cells/max_capacity/exponent");
+  p.produce_l = es.parameters.get<Real>("produce/l");
+  p.diffuse_c = es.parameters.get<Real>("diffuse/c"); p.mechano_c = es.parameters.get<Real>("mechano/c"); p.produce_c = es.parameters.get<Real>("produce/c");
+  p.necrosis_l = es.parameters.get<Real>("necrosis/l"); p.necrosis_c = es.parameters.get<Real>("necrosis/c");
+  p.necrosis_pressure = es.parameters.get<Real>("necrosis/pressure");
+  const MeshBase& mesh = es.get_mesh();
+  std::vector<double> xyz(3 * B.local_to_global_node.size());
+  for (size_t l = 0; l < B.local_to_global_node.size(); l++) {
+    const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+    for (unsigned int d = 0; d < 3; d++) xyz[3 * l + d] = nd(d);
+  }
+  if (rdc_mesh_update_coords(B.ctx, xyz.data()) != RDC_OK) fail(B.ctx, "rdc_mesh_update_coords");
+  gather_old_solution(es, system, B, 3);
+  if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
+  if (rdc_assemble_hcc(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_hcc");
+  push_results(es, system, B, 3);
+}
+
+// src/ripf.C:337-673: additionally reads TD vars 1, 2 (src/ripf.C:470-471) and RT var 2 (:477-478)
+void assemble_ripf(EquationSystems& es, const std::string& system_name) {
+  TransientLinearImplicitSystem& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  libmesh_assert_equal_to(system.n_vars(), 3);
+  const System& TD = es.get_system<System>("RIPF-TimeDeriv");
+  const System& RT = es.get_system<ExplicitSystem>("RT");
+  Binding& B = bind(es, system_name, 3);
+  rdc_ripf_params p;   // src/ripf.C:377-408
+  auto R = [&](const char* k) { return es.parameters.get<Real>(k); };
+  p.time_step = R("time_step");
+  p.VolFr_stroma = R("volume_fraction/stroma"); p.VolFr_parenchyma = R("volume_fraction/parenchyma");
+  p.VolFr_exponent = R("volume_fraction/exponent"); p.VolFr_min_vacant = R("volume_fraction/min_vacant");
+  p.VolFr_max_vacant = R("volume_fraction/max_vacant");
+  p.phi_cc_B = R("HU/phi/cc/build"); p.phi_cc_D = R("HU/phi/cc/decay"); p.phi_cc = R("HU/phi/cc/rate");
+  p.phi_fb_B = R("HU/phi/fb/build"); p.phi_fb_D = R("HU/phi/fb/decay"); p.phi_fb = R("HU/phi/fb/rate");
+  p.phi_tol = R("HU/phi/tolerance");
+  p.kappa = R("cc/kappa"); p.kappa_RT_c = R("cc/kappa/RT/c");
+  p.delta = R("cc/delta"); p.delta_RT_a = R("cc/delta/RT/a"); p.delta_RT_b = R("cc/delta/RT/b");
+  p.lambda = R("fb/lambda"); p.lambda_RT_r = R("fb/lambda/RT/r"); p.lambda_HU_r = R("fb/lambda/HU/r");
+  p.omicro = R("fb/omicro"); p.omicro_RT_r = R("fb/omicro/RT/r"); p.omicro_fb_b = R("fb/omicro/fb/b");
+  p.omega = R("fb/omega"); p.diffusion = R("fb/diffusion"); p.haptotaxis = R("fb/haptotaxis"); p.radiotaxis = R("fb/radiotaxis");
+  p.RT_dose_total_max = es.parameters.get<int>("RT_dose/total/max");
+  const MeshBase& mesh = es.get_mesh();
+  std::vector<double> aux(3 * B.local_to_global_node.size());
+  for (size_t l = 0; l < B.local_to_global_node.size(); l++) {
+    const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+    aux[3 * l + 0] = TD.current_solution(nd.dof_number(TD.number(), 1, 0));
+    aux[3 * l + 1] = TD.current_solution(nd.dof_number(TD.number(), 2, 0));
+    aux[3 * l + 2] = RT.current_solution(nd.dof_number(RT.number(), 2, 0));
+  }
+  gather_old_solution(es, system, B, 3);
+  if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
+  if (rdc_field_upload(B.ctx, RDC_FIELD_AUX_NODAL, aux.data(), (int64_t)aux.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(aux)");
+  if (rdc_assemble_ripf(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_ripf");
+  push_results(es, system, B, 3);
+}
+
+// assemble_adpm / assemble_proteas_model: same pattern; the exact parameter marshalling (incl. the elemental
+// "Tracts" system -> RDC_FIELD_ELEM_TRACTS and the nodal "AUX" system -> RDC_FIELD_AUX_NODAL) is spelled out and
+// tested in rdcfes_amd/host/rdc_host.h::assemble_adpm / assemble_proteas_model.  SolidSystem: override
+// FEMSystem::assembly(get_residual, get_jacobian) with rdc_solid_assemble.
 
 }  // namespace rdc_gpu
