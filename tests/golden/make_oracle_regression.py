@@ -6,7 +6,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from oracle import oracle as O
-from rdcfes_amd import SolidMaterial, SolidParams, hcc_params_from_dict, pihna_params_from_dict, ripf_params_from_dict, synth
+from rdcfes_amd import (SolidMaterial, SolidParams, adpm_params_from_dict, hcc_params_from_dict, pihna_params_from_dict,
+                        proteas_params_from_dict, ripf_params_from_dict, synth)
 
 
 def cases():
@@ -27,6 +28,10 @@ def cases():
     out["solid_hex8"] = O.assemble(3, 8, hconn, x, 3, SolidParams(0.4, 1e5, 0, 0), xyz_undeformed=hxyz,
                                    elem_fibre=np.tile([1.0, 2.0, 3.0], (hconn.shape[0], 1)),
                                    elem_material=np.zeros(hconn.shape[0], np.int32), materials=mats, sides=(se, ss, sd))[2:]
+    ua, tr = synth.adpm_fields(xyz, conn.shape[0])
+    out["adpm_tet4"] = O.assemble(4, 4, conn, xyz, 3, adpm_params_from_dict(synth.adpm_param_dict("full"), time=3.0), u_old=ua, elem_fibre=tr)[2:]
+    up, ax = synth.proteas_fields(hxyz)
+    out["proteas_hex8"] = O.assemble(5, 8, hconn, hxyz, 5, proteas_params_from_dict(synth.proteas_param_dict("full")), u_old=up, aux=ax)[2:]
     return out
 
 
