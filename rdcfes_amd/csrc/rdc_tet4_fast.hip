@@ -316,9 +316,16 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
       __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(recs + (p * nl_stride + wv * 64) * 2), 16, 0, 0);
   }
   if ((int)threadIdx.x < d.nnodes) ntab[threadIdx.x] = reinterpret_cast<const uint2*>(node_tab)[d.n0 + threadIdx.x];
-  const int nval = d.nb * NV * NV, ntot = nval + NDV * ns;
+  // The row slice starts one double into LDS when its first CSR value sits at an odd index, so that LDS and global
+  // memory have the same 16-byte phase and the store phase can move 16 bytes per lane; the private diagonal
+  // accumulators follow at the next even index (16-byte reads in the fold).
+  const int nval = d.nb * NV * NV, sh = (int)(d.vb0 & 1), dbase = (nval + sh + 1) & ~1, ntot = dbase + NDV * ns;
+  double* const sl = lds + sh;
   if (STAMP) tx[1] = __builtin_amdgcn_s_memtime();
-  for (int x = threadIdx.x; x < ntot; x += BLOCK) lds[x] = 0.0;
+  {  // 16-byte stores: half the LDS instructions of the zero phase, which queues behind the co-resident workgroup's atomics
+    double2* z = reinterpret_cast<double2*>(lds);
+    for (int x = threadIdx.x; x < ntot / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);  // ntot is even and <= acc_doubles
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed ...
   if (STAMP) tx[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();                                   // ... and so has everybody else's
@@ -345,9 +352,9 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
       }
     }
     LdsSink3<M, ABL> sink;
-    sink.row = lds + (ax.x & 0xFFFF);
+    sink.row = sl + (ax.x & 0xFFFF);
     sink.stride = (int)(ax.x >> 16);
-    sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
+    sink.dacc = lds + dbase + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
     sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
     sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
     const double* ED = nullptr;  // per-element inputs (ADPM tract vector): one more 4-byte list entry per pair
@@ -370,22 +377,30 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   if (STAMP) ts[3] = __builtin_amdgcn_s_memtime();
   for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
     const int v = x / d.nnodes, n = x - v * d.nnodes;
-    const double* src = lds + nval + v * ns + n * NC;
+    const double2* src = reinterpret_cast<const double2*>(lds + dbase + v * ns + n * NC);  // NC is even
     double sum = 0.0;
 #pragma unroll
-    for (int c = 0; c < NC; c++) sum += src[c];
+    for (int c = 0; c < NC / 2; c++) { const double2 t = src[c]; sum += t.x; sum += t.y; }
     if (v < NV * NV) {
       const uint2 nt = ntab[n];
       const int a = v / NV, b = v - a * NV;
-      lds[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + b] = sum;
+      sl[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + b] = sum;
     } else {
       rhs[(int64_t)(d.n0 + n) * NV + (v - NV * NV)] = sum;
     }
   }
   __syncthreads();
   if (STAMP) ts[4] = __builtin_amdgcn_s_memtime();
-  double* out = val + d.vb0;
-  for (int x = threadIdx.x; x < nval; x += BLOCK) __builtin_nontemporal_store(lds[x], out + x);
+  double* out = val + d.vb0;   // out[g] <-> sl[g]; out + sh and lds + 2 * sh are 16-byte aligned
+  {
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    const int npair = (nval - sh) >> 1;
+    const v2d_t* src = reinterpret_cast<const v2d_t*>(lds + 2 * sh);
+    v2d_t* dst = reinterpret_cast<v2d_t*>(out + sh);
+    for (int x = threadIdx.x; x < npair; x += BLOCK) __builtin_nontemporal_store(src[x], dst + x);
+    if (sh && threadIdx.x == 0) __builtin_nontemporal_store(sl[0], out);
+    if (((nval - sh) & 1) && threadIdx.x == 64) __builtin_nontemporal_store(sl[nval - 1], out + nval - 1);
+  }
   if (STAMP) {
     ts[5] = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0 && stamps) {
@@ -713,7 +728,7 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
       (a.opt_kernel == 0 || M::NELEM > 0 || M::AUX_LOCAL_NODE >= 0)) {
     constexpr int BLOCK = 256;
     const int nl = a.rg2.nl_stride;
-    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
+    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 3) & ~(size_t)1);  // + slice phase shift + diagonal alignment
     const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + (size_t)(Rec<M>::N / 2) * nl * 2);
 #define RDC_RG5(MINW, ST)                                                                                          \
   hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,     \
