@@ -155,8 +155,15 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
   const int64_t vb0 = (int64_t)NV * NV * m.bptr[n0];
   const int nval = (int)((int64_t)NV * NV * m.bptr[n1] - vb0);
   const int nrhs = (int)(n1 - n0) * NV;
-  double* lrhs = lds + nval;
-  for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
+  // the slice starts one double into LDS when its first CSR value has an odd index: LDS and global memory then share
+  // the 16-byte phase, and the zero / copy-out phases move 16 bytes per lane (the launch adds 16 bytes of LDS)
+  const int sh = (int)(vb0 & 1);
+  double* const sl = lds + sh;
+  double* lrhs = sl + nval;
+  {
+    double2* z = reinterpret_cast<double2*>(lds);
+    for (int x = threadIdx.x; x < (sh + nval + nrhs + 1) / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);
+  }
   __syncthreads();
   const int64_t p0 = m.node_pair_ptr[n0], p1 = m.node_pair_ptr[n1];
   // The pairs of one node are consecutive in the list and all add into the same diagonal block: consecutive
@@ -175,7 +182,7 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
     const int64_t I = m.conn[e * NEN + i];
     const int64_t b0 = m.bptr[I];
     const int len = (int)(m.bptr[I + 1] - b0);
-    double* row = lds + ((int64_t)NV * NV * b0 - vb0);
+    double* row = sl + ((int64_t)NV * NV * b0 - vb0);
     if constexpr (NV * NV * NEN > 128) {
       // The full NV x NV x NEN accumulator (200 doubles for five unknowns on HEX8) does not fit the register file
       // (hundreds of bytes of scratch per lane, 39 ms for 0.5 M hexes): one equation row at a time instead -- the
@@ -201,8 +208,16 @@ k_rowgather(const MeshDev m, const typename M::K k, const double* __restrict__ u
       __hip_atomic_fetch_add(lrhs + (I - n0) * NV + a, fe[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
-  double* out = val + vb0;
-  for (int x = threadIdx.x; x < nval; x += BLOCK) out[x] = lds[x];
+  double* out = val + vb0;  // out[g] <-> sl[g]; out + sh and lds + 2 * sh are 16-byte aligned
+  {
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    const int npair = (nval - sh) >> 1;
+    const v2d_t* src = reinterpret_cast<const v2d_t*>(lds + 2 * sh);
+    v2d_t* dst = reinterpret_cast<v2d_t*>(out + sh);
+    for (int x = threadIdx.x; x < npair; x += BLOCK) __builtin_nontemporal_store(src[x], dst + x);
+    if (sh && threadIdx.x == 0) out[0] = sl[0];
+    if (((nval - sh) & 1) && threadIdx.x == 64 % BLOCK) out[nval - 1] = sl[nval - 1];
+  }
   double* orhs = rhs + n0 * NV;
   for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
 }
@@ -225,9 +240,14 @@ k_rowgather_staged(const MeshDev m, const typename M::K k, const double* __restr
   const int64_t vb0 = (int64_t)NV * NV * m.bptr[n0];
   const int nval = (int)((int64_t)NV * NV * m.bptr[n1] - vb0);
   const int nrhs = (int)(n1 - n0) * NV;
-  double* lrhs = lds + nval;
+  const int sh = (int)(vb0 & 1);  // see k_rowgather
+  double* const sl = lds + sh;
+  double* lrhs = sl + nval;
   double* tab = lds + tab_off;
-  for (int x = threadIdx.x; x < nval + nrhs; x += BLOCK) lds[x] = 0.0;
+  {
+    double2* z = reinterpret_cast<double2*>(lds);
+    for (int x = threadIdx.x; x < (sh + nval + nrhs + 1) / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);
+  }
   {
     const int64_t l0 = nl_ptr[w];
     const int nn = (int)(nl_ptr[w + 1] - l0);
@@ -281,7 +301,7 @@ k_rowgather_staged(const MeshDev m, const typename M::K k, const double* __restr
     const int64_t I = m.conn[e * NEN + i];
     const int64_t b0 = m.bptr[I];
     const int len = (int)(m.bptr[I + 1] - b0);
-    double* row = lds + ((int64_t)NV * NV * b0 - vb0);
+    double* row = sl + ((int64_t)NV * NV * b0 - vb0);
 #pragma unroll
     for (int j = 0; j < NEN; j++) {
       const int s = m.eslot[e * (NEN * NEN) + i * NEN + j];
@@ -297,8 +317,16 @@ k_rowgather_staged(const MeshDev m, const typename M::K k, const double* __restr
       __hip_atomic_fetch_add(lrhs + (I - n0) * NV + a, fe[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
-  double* out = val + vb0;
-  for (int x = threadIdx.x; x < nval; x += BLOCK) out[x] = lds[x];
+  double* out = val + vb0;  // out[g] <-> sl[g]; out + sh and lds + 2 * sh are 16-byte aligned
+  {
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    const int npair = (nval - sh) >> 1;
+    const v2d_t* src = reinterpret_cast<const v2d_t*>(lds + 2 * sh);
+    v2d_t* dst = reinterpret_cast<v2d_t*>(out + sh);
+    for (int x = threadIdx.x; x < npair; x += BLOCK) __builtin_nontemporal_store(src[x], dst + x);
+    if (sh && threadIdx.x == 0) out[0] = sl[0];
+    if (((nval - sh) & 1) && threadIdx.x == 64 % BLOCK) out[nval - 1] = sl[nval - 1];
+  }
   double* orhs = rhs + n0 * NV;
   for (int x = threadIdx.x; x < nrhs; x += BLOCK) orhs[x] = lrhs[x];
 }

@@ -15,7 +15,7 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
       if constexpr (NEN == 8) {
         // node-staged form when the workgroup's row slice and node table fit 80 KB of LDS (two workgroups per CU)
         constexpr int REC = 3 + M::NV + (M::NAUX > 0 ? M::NAUX : 0);
-        const size_t tab_off = (a.lds_bytes / sizeof(double) + 1) & ~(size_t)1;
+        const size_t tab_off = (a.lds_bytes / sizeof(double) + 3) & ~(size_t)1;  // + slice phase shift, rounded to 16 bytes
         const size_t staged_bytes = sizeof(double) * (tab_off + (size_t)a.hx_max_nodes * REC);
         // opt_staged: 1 = where the model profits (M::HEX_STAGED), 2 = always, 0 = never
         if ((a.opt_staged == 2 || (a.opt_staged == 1 && M::HEX_STAGED)) && a.hx_ploc && staged_bytes <= 80 * 1024) {
@@ -30,7 +30,7 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
           return hipGetLastError();
         }
       }
-      hipLaunchKernelGGL((k_rowgather<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), a.lds_bytes,
+      hipLaunchKernelGGL((k_rowgather<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), a.lds_bytes + 16,
                          a.stream, a.m, k, a.u, a.aux, a.elem, a.val, a.rhs);
     }
     return hipGetLastError();
