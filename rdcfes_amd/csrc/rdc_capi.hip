@@ -47,6 +47,7 @@ struct rdc_ctx {
   DevBuf rg2_desc, rg2_pair, rg2_chunk, rg2_sdesc, rg2_contrib, rg2_aux, rg2_ntab, rg4_nlist, rg4_ploc;
   DevBuf hx_nl_ptr, hx_nlist, hx_ploc;   // node-staged generic row gather (HEX8)
   int opt_staged = 1;
+  DevBuf rg4_wgntab;
   DevBuf rg5_eid;             // pair -> element list, uploaded at the first assembly of a model with per-element inputs
   bool rg5_eid_ready = false;
   DevBuf field[RDC_FIELD_COUNT];
@@ -248,6 +249,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.node_tab = (const uint16_t*)c->rg2_ntab.p;
     if (c->prep.rg4_nl_stride > 0) {
       a.rg2.nlist = (const uint32_t*)c->rg4_nlist.p;
+      a.rg2.wg_ntab = (const uint16_t*)c->rg4_wgntab.p;
       a.rg2.pair_loc = (const uint32_t*)c->rg4_ploc.p;
       a.rg2.nl_stride = c->prep.rg4_nl_stride;
       if ((M::NELEM > 0 || M::AUX_LOCAL_NODE >= 0) && !c->prep.pair_eid.empty()) {
@@ -318,7 +320,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* all[] = {&c->conn, &c->xyz, &c->bptr, &c->eslot, &c->elem_order, &c->first_mask, &c->first_rhs,
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
-                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
+                   &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg4_wgntab, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
                    &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post};
   for (DevBuf* b : all) dev_free(c, *b);
@@ -433,6 +435,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
     if ((rc = dev_upload(c, c->rg2_ntab, P.node_tab))) return rc;
     if (P.rg4_nl_stride > 0) {
       if ((rc = dev_upload(c, c->rg4_nlist, P.nlist))) return rc;
+      if ((rc = dev_upload(c, c->rg4_wgntab, P.wg_ntab))) return rc;
       if ((rc = dev_upload(c, c->rg4_ploc, P.pair_loc))) return rc;
     }
   }

@@ -452,6 +452,14 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         }
       }
       if (fail_flag) P.rg2_ok = false;
+      if (P.rg2_ok && nen == 4) {
+        P.wg_ntab.assign((size_t)nwg * 16 * 4, 0);
+        for (int64_t w = 0; w < nwg; w++) {
+          const int nn = std::min<int>(P.wg2[(size_t)w].nnodes, 16);
+          std::copy(P.node_tab.begin() + (size_t)P.wg2[(size_t)w].n0 * 4, P.node_tab.begin() + ((size_t)P.wg2[(size_t)w].n0 + nn) * 4,
+                    P.wg_ntab.begin() + (size_t)w * 64);
+        }
+      }
       // ---- node lists of the workgroups (rg4) --------------------------------------------------
       if (P.rg2_ok && nen == 4) {
         std::vector<int32_t> nuniq((size_t)nwg, 0);
@@ -491,7 +499,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         }
       }
     }
-    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); P.nlist.clear(); P.pair_loc.clear(); P.pair_eid.clear(); P.rg4_nl_stride = 0; }
+    if (!P.rg2_ok) { P.wg2.clear(); P.pair_rec.clear(); P.chunk.clear(); P.sdesc.clear(); P.contrib.clear(); P.pair_aux.clear(); P.node_tab.clear(); P.nlist.clear(); P.pair_loc.clear(); P.pair_eid.clear(); P.wg_ntab.clear(); P.rg4_nl_stride = 0; }
   }
   return std::string();
 }

@@ -84,6 +84,7 @@ struct HostPrep {
   int rg4_nl_stride = 0;            // list length per workgroup (multiple of 64, max over workgroups)
   std::vector<uint32_t> nlist;      // [n_wg][rg4_nl_stride] node ids, padded with the first id
   std::vector<uint32_t> pair_loc;   // [n_wg][block] four 8-bit list indices (row node in the low byte); ~0u = no pair
+  std::vector<uint16_t> wg_ntab;    // [n_wg][16][4]: node_tab rows of the workgroup's nodes, for LDS-DMA by work-item index
   std::vector<uint32_t> pair_eid;   // [n_wg][block] element of the pair (uploaded only for models with per-element inputs)
   std::vector<Chunk> chunk;
   std::vector<StoreDesc> sdesc;     // [total node blocks]

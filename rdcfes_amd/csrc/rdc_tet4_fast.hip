@@ -419,34 +419,48 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
 }
 
 // ---- persistent, software-pipelined row gather -----------------------------------------------
-// Same arithmetic and LDS accumulation as k_tet4_rg3, but a workgroup loops over work items
-// (w = blockIdx.x, += gridDim.x) and, while it evaluates item w, the data of item w + gridDim.x is
-// already on its way into LDS by LDS-DMA (global_load_lds: no VGPR destination): the node records
-// of the item's distinct nodes (gathered through its node list) and its pair records.  A node
-// record is fetched once per workgroup instead of once per pair, pairs address nodes by 8-bit list
-// indices, and the ~2 us dependent load phase of every item overlaps the previous item's compute.
+// Same arithmetic and LDS accumulation as k_tet4_rg5, but a workgroup loops over work items (w = blockIdx.x,
+// += gridDim.x) and EVERYTHING an item needs arrives by LDS-DMA (global_load_lds: no VGPR destination) while earlier
+// items are being evaluated, in a three-stage pipeline:
+//   during item w      : node list of item w + 2G            -> nlbuf[(it + 2) % 3]
+//                        records (gathered through the node list of w + G, read from nlbuf[(it + 1) % 3]), pair
+//                        lists, descriptor and diagonal-slot table of item w + G -> item buffer (it + 1) & 1
+// No value loaded from global memory is held in a VGPR across the compute phase: the compute phase already uses all
+// 256 registers, and a spill costs far more here than elsewhere -- scratch traffic shares vmcnt with the DMA, so
+// every reload would wait for the whole prefetch (the first version of this kernel did exactly that: 3.8 ms).
 template <class M, int EXP_MODE, int BLOCK, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW)
 k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_loc,
            const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
-           const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
+           const uint16_t* __restrict__ wg_ntab, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int nwg, const int nl_stride,
-           const int acc_doubles) {
+           const int acc_doubles, const int stagger) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   constexpr int ns = HostPrep::RG3_DIAG_SLOTS, NP = Rec<M>::N / 2;  // NP 16-byte pieces per node record
+  constexpr int NTAB = 16;                                           // diagonal-slot table entries per item (uint2)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-  // LDS map: [accumulators: row slice | private diagonals] [2 x (records | pair_aux | pair_loc | descriptor)]
+  // LDS map: [accumulators] [2 x (records | pair_aux | pair_loc | descriptor | ntab)] [3 x node list]
   const int rec_doubles = NP * nl_stride * 2;
-  const int buf_doubles = rec_doubles + BLOCK * 2 + BLOCK / 2 + 8;
+  const int buf_doubles = rec_doubles + BLOCK * 2 + BLOCK / 2 + 8 + NTAB;
   double* const bufs = lds + acc_doubles;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int idx = lane * NW + wv;  // pair slot of this thread (see k_tet4_rg3)
+  uint32_t* const nlbuf = reinterpret_cast<uint32_t*>(bufs + 2 * buf_doubles);  // [3][nl_stride]
+  // thread-derived values are re-derived from an opaque copy of tt in every iteration (and the time-step
+  // factor every coefficient is multiplied with is made opaque, too): otherwise the compiler hoists the address
+  // arithmetic and the products of the model constants out of the item loop, runs out of registers and spills them
+  int tt = threadIdx.x, lane = tt & 63, wv = tt >> 6;
+  int idx = lane * NW + wv;  // pair slot of this thread (see k_tet4_rg3)
   const int rounds = nl_stride >> 6;
   const int G = gridDim.x;
 
-  // all LDS-DMA of one work item: records (wave r gathers list entries [64r, 64r+64)), pair records
+  auto dma_nlist = [&](int item, int slot) {
+    if (wv < rounds) {
+      const char* src = reinterpret_cast<const char*>(nlist + (size_t)item * nl_stride + wv * 64 + lane);
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(nlbuf + slot * nl_stride + wv * 64), 4, 0, 0);
+    }
+  };
+  // all LDS-DMA of one work item: records (wave r gathers list entries [64r, 64r+64)), pair lists, descriptor, ntab
   auto prefetch = [&](int item, uint32_t nid, int b) {
     double* base = bufs + b * buf_doubles;
     if (wv < rounds) {
@@ -455,41 +469,64 @@ k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
       for (int p = 0; p < NP; p++)
         __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(base + (p * nl_stride + wv * 64) * 2), 16, 0, 0);
     }
-    const char* ax = reinterpret_cast<const char*>(pair_aux) + ((size_t)item * BLOCK + threadIdx.x) * 16;
+    const char* ax = reinterpret_cast<const char*>(pair_aux) + ((size_t)item * BLOCK + tt) * 16;
     __builtin_amdgcn_global_load_lds((glb_ptr)ax, (lds_ptr)(base + rec_doubles + wv * 128), 16, 0, 0);
-    const char* pl = reinterpret_cast<const char*>(pair_loc) + ((size_t)item * BLOCK + threadIdx.x) * 4;
+    const char* pl = reinterpret_cast<const char*>(pair_loc) + ((size_t)item * BLOCK + tt) * 4;
     __builtin_amdgcn_global_load_lds((glb_ptr)pl, (lds_ptr)(base + rec_doubles + BLOCK * 2 + wv * 32), 4, 0, 0);
-    if (threadIdx.x < 4) {  // the 64-byte workgroup descriptor, too: a scalar load at the top of the item would expose a full memory latency
-      const char* dd = reinterpret_cast<const char*>(desc + item) + threadIdx.x * 16;
+    if (tt < 4) {  // the 64-byte workgroup descriptor
+      const char* dd = reinterpret_cast<const char*>(desc + item) + tt * 16;
       __builtin_amdgcn_global_load_lds((glb_ptr)dd, (lds_ptr)(base + rec_doubles + BLOCK * 2 + BLOCK / 2), 16, 0, 0);
+    } else if (tt >= 64 && tt < 64 + NTAB / 2) {  // 16 x 8 bytes of diagonal-slot table (wave 1)
+      const char* nt = reinterpret_cast<const char*>(wg_ntab) + ((size_t)item * NTAB) * 8 + (tt - 64) * 16;
+      __builtin_amdgcn_global_load_lds((glb_ptr)nt, (lds_ptr)(base + rec_doubles + BLOCK * 2 + BLOCK / 2 + 8), 16, 0, 0);
     }
   };
 
   int w = blockIdx.x;
   if (w >= nwg) return;
-  // ---- prologue: first item's data, second item's node ids; accumulators start at zero -------------
-  uint32_t nid_next = 0;
+  // optional: delay the second resident workgroup of every CU (dispatched in the second half of the grid) so the
+  // two do not run their phases in lock step
+  if (stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2)
+    for (int x = 0; x < stagger; x++) __builtin_amdgcn_s_sleep(127);
+  // ---- prologue: first item's data, second item's node list; accumulators start at zero -----------------
   {
     const uint32_t nid0 = (wv < rounds) ? nlist[(size_t)w * nl_stride + wv * 64 + lane] : 0u;
     prefetch(w, nid0, 0);
-    if (w + G < nwg && wv < rounds) nid_next = nlist[(size_t)(w + G) * nl_stride + wv * 64 + lane];
-    for (int x = threadIdx.x; x < acc_doubles; x += BLOCK) lds[x] = 0.0;
+    if (w + G < nwg) dma_nlist(w + G, 1);
+    double2* z = reinterpret_cast<double2*>(lds);
+    for (int x = tt; x < acc_doubles / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   for (int it = 0; w < nwg; it++, w += G) {
+    tt = threadIdx.x;
+    asm volatile("" : "+v"(tt));
+    lane = tt & 63; wv = tt >> 6; idx = lane * NW + wv;
+    typename M::K kk = k;
+    asm volatile("" : "+s"(kk.DT2));
     const int b = it & 1;
-    const HostPrep::WgDesc d = *reinterpret_cast<const HostPrep::WgDesc*>(bufs + b * buf_doubles + rec_doubles + BLOCK * 2 + BLOCK / 2);
-    const int wn = w + G;
-    uint32_t nid_n2 = 0;
-    if (wn < nwg) {  // buffer b^1 was last read before the barriers that ended the previous iteration
-      prefetch(wn, nid_next, b ^ 1);
-      if (wn + G < nwg && wv < rounds) nid_n2 = nlist[(size_t)(wn + G) * nl_stride + wv * 64 + lane];
-    }
     const double* base = bufs + b * buf_doubles;
+    // descriptor fields as scalars (an LDS read lands in VGPRs)
+    struct { int64_t vb0; int n0, nnodes, nb; } d;
+    {
+      const HostPrep::WgDesc* dp = reinterpret_cast<const HostPrep::WgDesc*>(base + rec_doubles + BLOCK * 2 + BLOCK / 2);
+      const int64_t vb = dp->vb0;
+      d.vb0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(vb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(vb & 0xFFFFFFFF));
+      d.n0 = __builtin_amdgcn_readfirstlane(dp->n0);
+      d.nnodes = __builtin_amdgcn_readfirstlane(dp->nnodes);
+      d.nb = __builtin_amdgcn_readfirstlane(dp->nb);
+    }
+    const uint2* ntab = reinterpret_cast<const uint2*>(base + rec_doubles + BLOCK * 2 + BLOCK / 2 + 8);
+    const int wn = w + G;
+    if (wn < nwg) {  // buffer b^1 and list slot (it+2)%3 were last read before the barriers that ended earlier iterations
+      const uint32_t nid = (wv < rounds) ? nlbuf[((it + 1) % 3) * nl_stride + wv * 64 + lane] : 0u;
+      prefetch(wn, nid, b ^ 1);
+      if (wn + G < nwg) dma_nlist(wn + G, (it + 2) % 3);
+    }
     const uint4 ax = reinterpret_cast<const uint4*>(base + rec_doubles)[idx];
     const uint32_t pl = reinterpret_cast<const uint32_t*>(base + rec_doubles + BLOCK * 2)[idx];
-    const int nval = d.nb * NV * NV;
+    const int nval = d.nb * NV * NV, sh = (int)(d.vb0 & 1), dbase = (nval + sh + 1) & ~1;  // see k_tet4_rg5
+    double* const sl = lds + sh;
     if (pl != 0xFFFFFFFFu) {
       double X[4][3], U[4][NV], AX[4][M::NAUX > 0 ? M::NAUX : 1];
 #pragma unroll
@@ -512,39 +549,45 @@ k_tet4_rg4(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
         }
       }
       LdsSink3<M> sink;
-      sink.row = lds + (ax.x & 0xFFFF);
+      sink.row = sl + (ax.x & 0xFFFF);
       sink.stride = (int)(ax.x >> 16);
-      sink.dacc = lds + nval + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
+      sink.dacc = lds + dbase + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
       sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
       sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
-      tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
+      tet4_row0<M, EXP_MODE>(kk, X, U, AX, sink);
     }
-    // the next item's LDS-DMA was issued a whole compute phase ago: this wait does not stall
+    // the DMA of the next items was issued a whole compute phase ago, and the stores of the previous item before
+    // that: this wait does not stall
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // fold the private copies (and clear them for the next item)
-    for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
+    for (int x = tt; x < d.nnodes * NDV; x += BLOCK) {
       const int v = x / d.nnodes, n = x - v * d.nnodes;
-      double* src = lds + nval + v * ns + n * NC;
+      double2* src = reinterpret_cast<double2*>(lds + dbase + v * ns + n * NC);
       double sum = 0.0;
 #pragma unroll
-      for (int c = 0; c < NC; c++) { sum += src[c]; src[c] = 0.0; }
+      for (int c = 0; c < NC / 2; c++) { const double2 t = src[c]; sum += t.x; sum += t.y; src[c] = make_double2(0.0, 0.0); }
       if (v < NV * NV) {
-        const uint2 nt = reinterpret_cast<const uint2*>(node_tab)[d.n0 + n];
+        const uint2 nt = ntab[n];
         const int a = v / NV, bb = v - a * NV;
-        lds[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + bb] = sum;
+        sl[(nt.x & 0xFFFF) + a * (int)(nt.x >> 16) + (nt.y & 0xFFFF) + bb] = sum;
       } else {
         rhs[(int64_t)(d.n0 + n) * NV + (v - NV * NV)] = sum;
       }
     }
     __syncthreads();
-    double* out = val + d.vb0;
-    for (int x = threadIdx.x; x < nval; x += BLOCK) {
-      __builtin_nontemporal_store(lds[x], out + x);
-      lds[x] = 0.0;  // accumulators are cleared by their last reader: no separate zero pass
+    double* out = val + d.vb0;  // out[g] <-> sl[g]; accumulators are cleared by their last reader: no separate zero pass
+    {
+      typedef double v2d_t __attribute__((ext_vector_type(2)));
+      const int npair = (nval - sh) >> 1;
+      v2d_t* src = reinterpret_cast<v2d_t*>(lds + 2 * sh);
+      v2d_t* dst = reinterpret_cast<v2d_t*>(out + sh);
+      const v2d_t zero2 = {0.0, 0.0};
+      for (int x = tt; x < npair; x += BLOCK) { __builtin_nontemporal_store(src[x], dst + x); src[x] = zero2; }
+      if (sh && tt == 0) { __builtin_nontemporal_store(sl[0], out); sl[0] = 0.0; }
+      if (((nval - sh) & 1) && tt == 64) { __builtin_nontemporal_store(sl[nval - 1], out + nval - 1); sl[nval - 1] = 0.0; }
     }
     __syncthreads();
-    nid_next = nid_n2;
   }
 }
 
@@ -711,18 +754,19 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
   // models with per-element inputs (M::NELEM > 0) or a local-node aux mask exist only as k_tet4_rg5 and k_tet4_coloured
   if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0)
-  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.wg_ntab && a.rg2.block == 256 &&
       a.opt_kernel == 4) {
     constexpr int BLOCK = 256;
     const int nl = a.rg2.nl_stride;
-    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
-    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + 2 * ((size_t)(Rec<M>::N / 2) * nl * 2 + BLOCK * 2 + BLOCK / 2 + 8));
+    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 3) & ~(size_t)1);
+    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + 2 * ((size_t)(Rec<M>::N / 2) * nl * 2 + BLOCK * 2 + BLOCK / 2 + 8 + 16) +
+                                                3 * (size_t)nl / 2);
     int grid = a.opt_grid > 0 ? a.opt_grid : 512;
     if (grid > a.rg2.n_wg) grid = a.rg2.n_wg;
 #define RDC_RG4(MINW)                                                                                              \
   hipLaunchKernelGGL((k_tet4_rg4<M, EXP_MODE, BLOCK, MINW>), dim3(grid), dim3(BLOCK), lds_bytes, a.stream, a.rg2.desc,    \
-                     a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, a.rg2.n_wg, nl, \
-                     acc_doubles)
+                     a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.wg_ntab, k, a.packed, a.val, a.rhs, a.rg2.n_wg, nl, \
+                     acc_doubles, a.opt_pf)
     if (a.opt_occ == 1) RDC_RG4(1); else RDC_RG4(2);
 #undef RDC_RG4
     return hipGetLastError();
