@@ -48,6 +48,7 @@ class HaloExchange:
             return out
         self.send_view = views(sb, lp.send_ids, self.send_peers)
         self.recv_view = views(rb, lp.recv_ids, self.recv_peers)
+        self._ops = None   # the P2POp list is the same every step: built once (needs the process group to exist)
 
     def exchange(self, u: torch.Tensor):
         """u: [n_node_local][nvar]; owned rows are read, ghost rows are overwritten in place."""
@@ -58,9 +59,10 @@ class HaloExchange:
             if self.host_staged:
                 self.send_host.copy_(self.send_buf, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-        ops = [dist.P2POp(dist.irecv, self.recv_view[q], q, group=self.group) for q in self.recv_peers]
-        ops += [dist.P2POp(dist.isend, self.send_view[q], q, group=self.group) for q in self.send_peers]
-        for w in dist.batch_isend_irecv(ops):
+        if self._ops is None:
+            self._ops = [dist.P2POp(dist.irecv, self.recv_view[q], q, group=self.group) for q in self.recv_peers]
+            self._ops += [dist.P2POp(dist.isend, self.send_view[q], q, group=self.group) for q in self.send_peers]
+        for w in dist.batch_isend_irecv(self._ops):
             w.wait()
         if self.recv_idx.numel():
             if self.host_staged:
