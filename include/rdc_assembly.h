@@ -187,7 +187,13 @@ int rdc_set_scatter(rdc_ctx* ctx, int strategy);
 int rdc_get_scatter(const rdc_ctx* ctx, int* strategy);
 int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
 /* tuning / profiling knobs, not needed for normal use.  "occupancy": launch-bound waves per SIMD of
- * the TET4 row-gather kernel; "ablate": 1/2 remove parts of that kernel (results are then WRONG) */
+ * the TET4 row-gather kernel; "ablate": 1/2 remove parts of that kernel (results are then WRONG).
+ * Two-part assembly, for overlapping a halo exchange with the assembly of rows that do not need it:
+ * "interior_nodes" = n states that no element of the owned nodes [0, n) contains a ghost node (the caller numbers
+ * its owned nodes interior-first); with "part" = 1 an assemble call then writes only the rows of leading workgroups
+ * inside [0, n), with "part" = 2 the remaining rows, with "part" = 0 (default) all rows.  Part 1 followed by part 2
+ * gives exactly the matrix and residual of one whole call.  Paths that cannot launch sub-ranges (HEX8, the
+ * coloured strategy, the solid system) write nothing in part 1 and everything in part 2. */
 int rdc_set_option(rdc_ctx* ctx, const char* key, int value);
 
 /* ---- mesh / pattern (one-time set-up; replaces es.init()) ---- */

@@ -36,6 +36,8 @@ struct rdc_ctx {
   int opt_grid = 0;     // persistent grid size of the pipelined kernel (0 = 2 workgroups per CU)
   int opt_sched = 1;    // LDS-conflict-aware pair schedule (takes effect at the next rdc_mesh_upload)
   int opt_special = 1;  // allow parameter-sparsity kernel variants
+  int opt_part = 0;            // 0 = whole mesh, 1 = workgroups of interior nodes only, 2 = the remaining workgroups
+  int64_t opt_interior = -1;   // owned nodes [0, opt_interior) have no ghost node in any of their elements
   int opt_slim = 0;     // PIHNA: slim per-point state (re-derived per equation row); with occupancy=3 three waves per SIMD
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
@@ -263,6 +265,29 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
     a.rg2.block = c->prep.rg2_block;
   }
+  if (c->opt_part != 0) {
+    // two-part assembly (halo overlap): part 1 = the leading workgroups whose nodes are all interior, part 2 = the
+    // rest.  Only the default TET4 row-gather kernel launches sub-ranges; every other path assembles everything in
+    // part 2 and nothing in part 1.
+    const bool sub = a.nen == 4 && a.strategy == RDC_SCATTER_ROWGATHER && a.variant != RDC_VARIANT_GENERIC && a.rg2.n_wg > 0 &&
+                     a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 && a.opt_kernel == 0 && c->opt_interior >= 0 &&
+                     ((M::NELEM == 0 && M::AUX_LOCAL_NODE < 0) || a.rg2.pair_eid);
+    int split = 0;
+    if (sub) {
+      int lo = 0, hi = a.rg2.n_wg;  // first workgroup reaching beyond the interior nodes
+      while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if ((int64_t)c->prep.wg2[(size_t)mid].n0 + c->prep.wg2[(size_t)mid].nnodes <= c->opt_interior) lo = mid + 1; else hi = mid;
+      }
+      split = lo;
+    }
+    if (c->opt_part == 1) {
+      if (!sub || split == 0) return RDC_OK;
+      a.rg2.wg_begin = 0; a.rg2.wg_count = split;
+    } else {
+      a.rg2.wg_begin = split; a.rg2.wg_count = -1;
+    }
+  }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
   a.stream = c->stream;
@@ -369,6 +394,11 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   }
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
   else if (!std::strcmp(key, "slim")) c->opt_slim = value;
+  else if (!std::strcmp(key, "interior_nodes")) c->opt_interior = value;  // see rdc_assembly.h (two-part assembly)
+  else if (!std::strcmp(key, "part")) {
+    if (value < 0 || value > 2) return fail(c, RDC_ERR_INVALID, "part must be 0, 1 or 2");
+    c->opt_part = value;
+  }
   else if (!std::strcmp(key, "staged")) c->opt_staged = value;  // HEX8 generic row gather: node table in LDS (default 1)
   else if (!std::strcmp(key, "xcd")) c->opt_xcd = value;
   else if (!std::strcmp(key, "schedule")) c->opt_sched = value;
@@ -647,6 +677,9 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   a.side_disp = (const double*)c->side_disp.p;
   a.params = *p;
   a.request_jacobian = request_jacobian;
+  // two-part assembly (halo overlap) is a feature of the reaction-diffusion row-gather kernel: the solid system
+  // assembles everything in part 2
+  if (c->opt_part == 1) return RDC_OK;
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
   a.stream = c->stream;

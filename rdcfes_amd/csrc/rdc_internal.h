@@ -25,6 +25,7 @@ struct Rg2Dev {
   const uint16_t* node_tab = nullptr;
   const uint32_t* nlist = nullptr;
   const uint32_t* pair_loc = nullptr;
+  int wg_begin = 0, wg_count = -1;      // sub-range of the work items to launch (k_tet4_rg5 only; -1 = all)
   const uint16_t* wg_ntab = nullptr;    // [n_wg][16][4]: node_tab entries of the workgroup's nodes (persistent kernel)
   const uint32_t* pair_eid = nullptr;   // element of the pair (models with per-element inputs only)
   int nl_stride = 0;

@@ -267,7 +267,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
            const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
            long long* __restrict__ stamps, const int pf_dist, const int xcd_remap,
-           const uint32_t* __restrict__ pair_eid, const double* __restrict__ elem) {
+           const uint32_t* __restrict__ pair_eid, const double* __restrict__ elem, const int wg_begin) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
@@ -281,6 +281,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     const int q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
     w = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
   }
+  w += wg_begin;  // sub-range launches (interior rows before the halo exchange has landed, the rest after)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = lane * NW + wv;
   double* const recs = lds + acc_doubles;
@@ -777,21 +778,23 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     const int nl = a.rg2.nl_stride;
     const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 3) & ~(size_t)1);  // + slice phase shift + diagonal alignment
     const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + (size_t)(Rec<M>::N / 2) * nl * 2);
+    const int wg_begin = a.rg2.wg_begin, wg_count = a.rg2.wg_count < 0 ? a.rg2.n_wg - a.rg2.wg_begin : a.rg2.wg_count;
+    if (wg_count <= 0) return hipSuccess;
 #define RDC_RG5(MINW, ST)                                                                                          \
-  hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,     \
+  hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,     \
                      a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
-                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem)
+                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin)
     if constexpr (std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) {
       // diagnostic builds (timing only, results are wrong): LDS atomics replaced by plain stores / removed
       if (a.opt_ablate == 1 || a.opt_ablate == 2) {
         if (a.opt_ablate == 1)
-          hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 1>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,
+          hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 1>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,
                              a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs,
-                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem);
+                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin);
         else
-          hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 2>), dim3(a.rg2.n_wg), dim3(BLOCK), lds_bytes, a.stream,
+          hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 2>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,
                              a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs,
-                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem);
+                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin);
         return hipGetLastError();
       }
     }

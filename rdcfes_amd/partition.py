@@ -71,6 +71,7 @@ class LocalPartition:
     node_global: np.ndarray   # local node id -> global node id
     elem_global: np.ndarray   # local element id -> global element id
     n_elem_owned: int         # elements of this partition in the global partition (metric accounting)
+    n_interior: int = 0       # leading owned nodes whose elements contain no ghost node (assembled before the halo lands)
     # halo plan: for every peer q, the local ids to send (owned here, ghost on q) and to receive
     send_ids: dict = field(default_factory=dict)
     recv_ids: dict = field(default_factory=dict)
@@ -100,12 +101,19 @@ def build_local(conn: np.ndarray, xyz: np.ndarray, elem_part: np.ndarray, rank: 
     assert owned.size == int(owned_mask.sum())
     ghosts = touched[~owned_mask[touched]]
     ghosts = ghosts[np.lexsort((ghosts, owner[ghosts]))]
+    # owned nodes none of whose elements contains a ghost node come first: their rows can be assembled while the halo
+    # exchange of the step is still in flight (bench.py overlaps the two); the order inside both groups is kept
+    ce = conn[elems]
+    near_ghost = np.zeros(n_node, dtype=bool)
+    near_ghost[np.unique(ce[(~owned_mask[ce]).any(axis=1)])] = True
+    interior = owned[~near_ghost[owned]]
+    owned = np.concatenate([interior, owned[near_ghost[owned]]])
     node_global = np.concatenate([owned, ghosts])
     g2l = np.full(n_node, -1, dtype=np.int64)
     g2l[node_global] = np.arange(node_global.size)
     lp = LocalPartition(rank=rank, nparts=nparts, conn=g2l[conn[elems]].astype(np.uint32), xyz=xyz[node_global],
                         n_owned=owned.size, node_global=node_global, elem_global=elems,
-                        n_elem_owned=int((elem_part == rank).sum()))
+                        n_elem_owned=int((elem_part == rank).sum()), n_interior=int(interior.size))
     for q in range(nparts):
         if q == rank:
             continue

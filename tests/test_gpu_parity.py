@@ -287,9 +287,17 @@ def _two_rank_worker(rank, world, port, q):
             ctx.set_stream(torch.cuda.current_stream().cuda_stream)
             ctx.mesh_upload(4, lp.conn, lp.xyz, 5, n_owned=lp.n_owned)
             ctx.field_bind_device(FIELD_OLD_SOLUTION, u_l.data_ptr(), u_l.numel())
+            # two-part assembly as bench.py overlaps it: the interior rows are assembled while the ghost values are
+            # still NaN (nothing on them may read a ghost), the remaining rows after the exchange
+            ctx.set_option("interior_nodes", int(lp.n_interior))
+            ctx.set_option("part", 1)
+            ctx.assemble_pihna(p)
+            ctx.synchronize()
             hx.exchange(u_l)
+            ctx.set_option("part", 2)
             ctx.assemble_pihna(p)
             val, rhs = ctx.csr_download()
+            assert np.isfinite(val).all() and np.isfinite(rhs).all()
             rp, col = ctx.csr_pattern()
         # reference: the global assembly restricted to this rank's rows
         grp, gcol, gval, grhs = O.assemble(0, 4, conn, xyz, 5, p, u_old=u)
@@ -347,3 +355,43 @@ def test_pihna_option_sets(oracle, opts):
         ctx.assemble_pihna(p)
         val, rhs = ctx.csr_download()
     assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
+
+
+@pytest.mark.parametrize("frac", [0.0, 0.37, 1.0])
+def test_two_part_assembly_equals_whole(frac):
+    """rdc_set_option("part", 1|2): the rows of the leading workgroups inside [0, interior_nodes) and then the rest give
+    the matrix and residual of one whole call (to round-off: the order of the LDS atomic adds is not fixed), and
+    part 1 writes nothing outside its rows."""
+    conn, xyz = synth.kuhn_tet_mesh(12, order="lex")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    n_int = int(frac * xyz.shape[0])
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val0, rhs0 = ctx.csr_download()
+        rp, _ = ctx.csr_pattern()
+        ctx.field_upload(FIELD_OLD_SOLUTION, 0.5 * u)      # overwrite every row with something else
+        ctx.assemble_pihna(p)
+        val1, rhs1 = ctx.csr_download()
+        assert not np.array_equal(val0, val1)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.set_option("interior_nodes", n_int)
+        ctx.set_option("part", 1)
+        ctx.assemble_pihna(p)
+        vala, rhsa = ctx.csr_download()
+        ctx.set_option("part", 2)
+        ctx.assemble_pihna(p)
+        valb, rhsb = ctx.csr_download()
+        ctx.set_option("part", 0)
+    row_of = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+    new_rows = np.union1d(np.flatnonzero(rhsa != rhs1), np.unique(row_of[vala != val1]))
+    assert new_rows.size == 0 or new_rows.max() < 5 * n_int          # part 1 stays inside the interior rows
+    if frac == 1.0:
+        assert rel(vala, val0) < 1e-13 and rel(rhsa, rhs0) < 1e-13
+    elif frac > 0:
+        assert new_rows.size > 0.5 * 5 * n_int                       # ... and covers most of them
+    first_untouched = 5 * n_int
+    assert np.array_equal(vala[rp[first_untouched]:], val1[rp[first_untouched]:])
+    assert rel(valb, val0) < 1e-13 and rel(rhsb, rhs0) < 1e-13

@@ -37,6 +37,12 @@ def test_local_partitions_cover_mesh_and_halo_plan_is_symmetric(nparts):
         g = lp.node_global[lp.conn.astype(np.int64)]
         np.testing.assert_array_equal(g, conn[lp.elem_global])
         assert np.all((lp.conn < lp.n_owned).any(axis=1))
+        # interior-first numbering: an element of an interior node has no ghost node; every other owned node has one
+        assert 0 <= lp.n_interior <= lp.n_owned
+        has_ghost = (lp.conn >= lp.n_owned).any(axis=1)
+        near = np.zeros(lp.node_global.size, dtype=bool)
+        near[lp.conn[has_ghost].ravel()] = True
+        assert not near[:lp.n_interior].any() and near[lp.n_interior:lp.n_owned].all()
         for q, ids in lp.recv_ids.items():
             assert np.all(ids >= lp.n_owned)
             other = lps[q]
