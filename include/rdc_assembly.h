@@ -294,6 +294,31 @@ typedef struct rdc_pihna_ranges {
 } rdc_pihna_ranges;
 int rdc_pihna_volume_integrals(rdc_ctx* ctx, const rdc_pihna_ranges* r, int64_t n_elem, double* out4);
 
+/* RIPF save_solution (replaces the element loop of src/ripf.C:812-858): out[2] = {Tumour_Volume, Fibrosis_Volume},
+ * the volume of the elements ALL of whose nodes have HU inside [HU_min, HU_max] and cc (fb) >= min; read from
+ * RDC_FIELD_OLD_SOLUTION (3 unknowns HU, cc, fb); first n_elem elements, -1 for all; with several ranks add. */
+typedef struct rdc_ripf_ranges {
+  double cc_HU_min, cc_HU_max, cc_min;   /* "range_cc/HU/min,max", "range_cc/min" */
+  double fb_HU_min, fb_HU_max, fb_min;   /* "range_fb/HU/min,max", "range_fb/min" */
+} rdc_ripf_ranges;
+int rdc_ripf_volume_integrals(rdc_ctx* ctx, const rdc_ripf_ranges* r, int64_t n_elem, double* out2);
+
+/* ADPM save_solution (replaces the element loop of src/adpm.C:747-813) over the brain parcellation = the set of
+ * subdomain ids: elem_subdomain[n_elem] is elem->subdomain_id(), ids[n_ids] the parcellation (ascending, as the
+ * std::set iterates).  out[n_ids][4] = {CONCENTRATION__A_b, CONCENTRATION__Tau, VOLUME__A_b, VOLUME__Tau}: the
+ * volumes sum the elements of the region ALL of whose nodes lie inside the range (add over ranks); the
+ * concentrations are -- as upstream, which assigns instead of accumulating (:780-783) -- the element average
+ * sum_qp JxW*value / volume of the LAST element of the region in element order, and last_elem[n_ids] (may be
+ * NULL) returns that element (-1: region empty here) so that several ranks can keep the one with the highest
+ * global element.  Unknowns (PrP, A_b, Tau) from RDC_FIELD_OLD_SOLUTION (nvar = 3).  n_ids <= 2048. */
+typedef struct rdc_adpm_ranges {
+  double A_b_min, A_b_max;   /* "range/A_b/min,max" */
+  double Tau_min, Tau_max;   /* "range/Tau/min,max" */
+} rdc_adpm_ranges;
+int rdc_adpm_parcellation_integrals(rdc_ctx* ctx, const rdc_adpm_ranges* r, const int32_t* elem_subdomain,
+                                    const int32_t* ids, int32_t n_ids, int64_t n_elem, double* out,
+                                    int64_t* last_elem);
+
 /* ---- instrumentation ---- */
 /* when enabled every rdc_assemble_* brackets its dominant kernel(s) -- the assembly kernel, or all
  * colour launches; not the small node-record pack -- with HIP events on the context stream */

@@ -187,6 +187,32 @@ def pihna_volume_integrals(elem_type, conn, xyz, u, ranges, n_elem=None):
     return out
 
 
+def ripf_volume_integrals(elem_type, conn, xyz, u, ranges, n_elem=None):
+    conn = np.ascontiguousarray(conn, dtype=np.uint32)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(2)
+    ne = conn.shape[0] if n_elem is None else n_elem
+    rc = lib().oracle_ripf_volume_integrals(int(elem_type), C.c_int64(ne), _p(conn, C.c_uint32), _p(xyz), _p(u), C.byref(ranges), _p(out))
+    assert rc == 0
+    return out
+
+
+def adpm_parcellation_integrals(elem_type, conn, xyz, u, ranges, elem_subdomain, ids, n_elem=None):
+    """-> [n_ids][4] = A_b concentration, Tau concentration, A_b volume, Tau volume per parcellation id"""
+    conn = np.ascontiguousarray(conn, dtype=np.uint32)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    sub = np.ascontiguousarray(elem_subdomain, dtype=np.int32)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    out = np.zeros((ids.size, 4))
+    ne = conn.shape[0] if n_elem is None else n_elem
+    rc = lib().oracle_adpm_parcellation_integrals(int(elem_type), C.c_int64(ne), _p(conn, C.c_uint32), _p(xyz), _p(u), C.byref(ranges),
+                                                  _p(sub, C.c_int32), _p(ids, C.c_int32), C.c_int32(ids.size), _p(out))
+    assert rc == 0
+    return out
+
+
 def ripf_check_solution(params, sol, prev, rt):
     """-> (clamped solution, new prev, time derivative, rt with total, aux, RT_total_max)"""
     cp = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()

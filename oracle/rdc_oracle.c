@@ -1276,6 +1276,85 @@ int oracle_pihna_volume_integrals(int elem_type, int64_t n_elem, const uint32_t*
   return 0;
 }
 
+/* RIPF save_solution, the element loop of src/ripf.C:812-858: out = {tumour_volume, fibrosis_volume} */
+int oracle_ripf_volume_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz, const double* u,
+                                 const rdc_ripf_ranges* r, double* out) {
+  const int nen = elem_type, nqp = oracle_nqp(elem_type);
+  if (nqp < 0) return 1;
+  double X[8 * 3], phi[8 * 8], dphi[8 * 8 * 3], JxW[8];
+  out[0] = out[1] = 0.0;
+  for (int64_t e = 0; e < n_elem; e++) {
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++)
+      for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+    oracle_fe_reinit(elem_type, X, phi, dphi, JxW);
+    double Volume = 0.0; /* elem->volume() */
+    for (int q = 0; q < nqp; q++) Volume += JxW[q];
+    int do_include = 1; /* :832-842 */
+    for (int l = 0; l < nen && do_include; l++) {
+      const double HU = u[3 * (int64_t)c[l]], cc = u[3 * (int64_t)c[l] + 1];
+      if (!(HU >= r->cc_HU_min && HU <= r->cc_HU_max && cc >= r->cc_min)) do_include = 0;
+    }
+    if (do_include) out[0] += Volume;
+    do_include = 1; /* :844-854 */
+    for (int l = 0; l < nen && do_include; l++) {
+      const double HU = u[3 * (int64_t)c[l]], fb = u[3 * (int64_t)c[l] + 2];
+      if (!(HU >= r->fb_HU_min && HU <= r->fb_HU_max && fb >= r->fb_min)) do_include = 0;
+    }
+    if (do_include) out[1] += Volume;
+  }
+  return 0;
+}
+
+/* ADPM save_solution, the element loop of src/adpm.C:747-813.  out[n_ids][4] = {A_b concentration, Tau
+ * concentration, A_b volume, Tau volume} per parcellation id.  The concentrations are ASSIGNED per element upstream
+ * (:780-783), so the value of the last element of the region survives; regions without elements keep 0 (a
+ * default-constructed std::map entry). */
+int oracle_adpm_parcellation_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
+                                       const double* u, const rdc_adpm_ranges* r, const int32_t* elem_subdomain,
+                                       const int32_t* ids, int32_t n_ids, double* out) {
+  const int nen = elem_type, nqp = oracle_nqp(elem_type);
+  if (nqp < 0) return 1;
+  double X[8 * 3], phi[8 * 8], dphi[8 * 8 * 3], JxW[8];
+  for (int32_t i = 0; i < 4 * n_ids; i++) out[i] = 0.0;
+  for (int64_t e = 0; e < n_elem; e++) {
+    int32_t slot = -1;
+    for (int32_t i = 0; i < n_ids; i++) if (ids[i] == elem_subdomain[e]) { slot = i; break; }
+    if (slot < 0) continue;
+    const uint32_t* c = conn + e * nen;
+    for (int i = 0; i < nen; i++)
+      for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
+    oracle_fe_reinit(elem_type, X, phi, dphi, JxW);
+    double Volume = 0.0;
+    for (int q = 0; q < nqp; q++) Volume += JxW[q];
+    double A_b__average = 0.0, Tau__average = 0.0; /* :766-778 */
+    for (int q = 0; q < nqp; q++) {
+      double A_b = 0.0, Tau = 0.0;
+      for (int l = 0; l < nen; l++) {
+        A_b += phi[q * nen + l] * u[3 * (int64_t)c[l] + 1];
+        Tau += phi[q * nen + l] * u[3 * (int64_t)c[l] + 2];
+      }
+      A_b__average += JxW[q] * A_b;
+      Tau__average += JxW[q] * Tau;
+    }
+    out[4 * slot] = A_b__average / Volume;     /* :780 */
+    out[4 * slot + 1] = Tau__average / Volume; /* :783 */
+    int consider = 1; /* :787-798 */
+    for (int n = 0; n < nen; n++) {
+      const double A_b = u[3 * (int64_t)c[n] + 1];
+      if (!(A_b >= r->A_b_min && A_b <= r->A_b_max)) { consider = 0; break; }
+    }
+    if (consider) out[4 * slot + 2] += Volume;
+    consider = 1; /* :801-812 */
+    for (int n = 0; n < nen; n++) {
+      const double Tau = u[3 * (int64_t)c[n] + 2];
+      if (!(Tau >= r->Tau_min && Tau <= r->Tau_max)) { consider = 0; break; }
+    }
+    if (consider) out[4 * slot + 3] += Volume;
+  }
+  return 0;
+}
+
 /* check_solution negativity clamp, src/pihna.C:785-790 */
 void oracle_clamp_nonnegative(double* u, int64_t n) {
   for (int64_t i = 0; i < n; i++) if (u[i] < 0.0) u[i] = 0.0;

@@ -42,6 +42,11 @@ void oracle_proteas_element(int nen, int nqp, const double* phi, const double* d
                             const double* u, const double* aux0, const rdc_proteas_params* P, double* Ke, double* Fe);
 int oracle_pihna_volume_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz, const double* u,
                                   const rdc_pihna_ranges* r, double* out);
+int oracle_ripf_volume_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz, const double* u,
+                                 const rdc_ripf_ranges* r, double* out);
+int oracle_adpm_parcellation_integrals(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
+                                       const double* u, const rdc_adpm_ranges* r, const int32_t* elem_subdomain,
+                                       const int32_t* ids, int32_t n_ids, double* out);
 void oracle_clamp_nonnegative(double* u, int64_t n);
 int oracle_solid_post_process(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
                               const double* xyz_undeformed, const double* elem_fibre, const int32_t* elem_material,

@@ -5,7 +5,7 @@ This Python package is the test / benchmark harness above that ABI plus the host
 logic; it contains no numerical fallback: without the built library and a GPU every compute call
 raises.
 """
-from .params import (PihnaParams, RipfParams, HccParams, SolidParams, SolidMaterial, RipfCheckParams, AdpmParams, ProteasParams, PihnaRanges,
+from .params import (PihnaParams, RipfParams, HccParams, SolidParams, SolidMaterial, RipfCheckParams, AdpmParams, ProteasParams, PihnaRanges, RipfRanges, AdpmRanges,
                      pihna_params_from_dict, ripf_params_from_dict, hcc_params_from_dict,
                      adpm_params_from_dict, proteas_params_from_dict)
 from .context import (AssemblyContext, RdcError, TET4, HEX8, SCATTER_AUTO, SCATTER_COLOURED,
@@ -14,7 +14,7 @@ from .context import (AssemblyContext, RdcError, TET4, HEX8, SCATTER_AUTO, SCATT
                       FIELD_RT_DOSE, FIELD_ELEM_TRACTS)
 
 __all__ = [
-    "PihnaParams", "RipfParams", "HccParams", "SolidParams", "SolidMaterial", "RipfCheckParams", "AdpmParams", "adpm_params_from_dict", "ProteasParams", "proteas_params_from_dict", "PihnaRanges",
+    "PihnaParams", "RipfParams", "HccParams", "SolidParams", "SolidMaterial", "RipfCheckParams", "AdpmParams", "adpm_params_from_dict", "ProteasParams", "proteas_params_from_dict", "PihnaRanges", "RipfRanges", "AdpmRanges",
     "pihna_params_from_dict", "ripf_params_from_dict", "hcc_params_from_dict",
     "AssemblyContext", "RdcError", "TET4", "HEX8", "SCATTER_AUTO", "SCATTER_COLOURED",
     "SCATTER_ROWGATHER", "FIELD_OLD_SOLUTION", "FIELD_AUX_NODAL", "FIELD_UNDEFORMED_XYZ",

@@ -49,6 +49,9 @@ SIGNATURES = {
     "rdc_assemble_proteas": (C.c_int, [ctx_p, C.c_void_p]),
     "rdc_clamp_nonnegative": (C.c_int, [ctx_p, C.c_int]),
     "rdc_pihna_volume_integrals": (C.c_int, [ctx_p, C.c_void_p, i64, C.POINTER(C.c_double)]),
+    "rdc_ripf_volume_integrals": (C.c_int, [ctx_p, C.c_void_p, i64, C.POINTER(C.c_double)]),
+    "rdc_adpm_parcellation_integrals": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, i64,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "rdc_solid_post_process": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdc_ripf_check_solution": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_double)]),
     "rdc_timing_enable": (C.c_int, [ctx_p, C.c_int]),

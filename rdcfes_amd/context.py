@@ -150,6 +150,25 @@ class AssemblyContext:
         self._ck(self._lib.rdc_pihna_volume_integrals(self._h, C.byref(ranges), int(n_elem), _dp(out)))
         return out
 
+    def ripf_volume_integrals(self, ranges, n_elem=-1):
+        """Tumour_Volume, Fibrosis_Volume of RIPF's CSV line (src/ripf.C:777-866) over the first n_elem elements"""
+        out = np.zeros(2)
+        self._ck(self._lib.rdc_ripf_volume_integrals(self._h, C.byref(ranges), int(n_elem), _dp(out)))
+        return out
+
+    def adpm_parcellation_integrals(self, ranges, elem_subdomain, ids, n_elem=-1):
+        """ADPM's CSV line (src/adpm.C:690-829): -> ([n_ids][4] = A_b concentration, Tau concentration, A_b volume,
+        Tau volume per parcellation id; last element of every region, -1 if it has none here)"""
+        sub = np.ascontiguousarray(elem_subdomain, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if sub.size < (self.n_elem if n_elem < 0 else n_elem):
+            raise ValueError("elem_subdomain shorter than the element range")
+        out, last = np.zeros((ids.size, 4)), np.full(ids.size, -1, dtype=np.int64)
+        self._ck(self._lib.rdc_adpm_parcellation_integrals(
+            self._h, C.byref(ranges), sub.ctypes.data_as(C.POINTER(C.c_int32)), ids.ctypes.data_as(C.POINTER(C.c_int32)),
+            int(ids.size), int(n_elem), _dp(out), last.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out, last
+
     def solid_post_process(self, params):
         """SolidSystem::post_process -> (pressure [ne], von_mises [ne], fibre_current [ne][3])"""
         pr, vm, fc = np.empty(self.n_elem), np.empty(self.n_elem), np.empty((self.n_elem, 3))

@@ -57,6 +57,7 @@ struct rdc_ctx {
   DevBuf wg_max;  // per-workgroup maxima of rdc_ripf_check_solution
   // solid
   DevBuf elem_material, materials, side_elem, side_id, side_disp;
+  DevBuf adpm_slot;
   DevBuf solid_ke, solid_fe, sg_gptr, sg_gsrc, sg_brow, solid_post;  // two-pass assembly: element matrices + gather lists
   bool solid_gather_ready = false;
   int opt_solid_kernel = 0;  // 0 = two-pass (default), 1 = coloured read-modify-write
@@ -347,7 +348,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg4_wgntab, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
-                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post};
+                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -478,7 +479,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   RDC_HIP(c, hipStreamSynchronize(c->stream));
   // fields are tied to the mesh sizes: drop library-owned ones
   for (int f = 0; f < RDC_FIELD_COUNT; f++) { dev_free(c, c->field[f]); c->field_count[f] = 0; }
-  dev_free(c, c->elem_material); dev_free(c, c->materials);
+  dev_free(c, c->elem_material); dev_free(c, c->materials); dev_free(c, c->adpm_slot);
   dev_free(c, c->side_elem); dev_free(c, c->side_id); dev_free(c, c->side_disp);
   c->n_materials = 0; c->n_sides = 0;
   c->have_mesh = true;
@@ -789,6 +790,101 @@ int rdc_pihna_volume_integrals(rdc_ctx* c, const rdc_pihna_ranges* r, int64_t n_
     double s = 0.0;
     for (int64_t g = 0; g < grid; g++) s += h[(size_t)g * 4 + x];
     out4[x] = s;
+  }
+  return RDC_OK;
+}
+
+int rdc_ripf_volume_integrals(rdc_ctx* c, const rdc_ripf_ranges* r, int64_t n_elem, double* out2) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!r || !out2) return fail(c, RDC_ERR_INVALID, "null argument");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (c->prep.nvar != 3) return fail(c, RDC_ERR_INVALID, "RIPF volume integrals need nvar=3");
+  if (!c->field[RDC_FIELD_OLD_SOLUTION].p) return fail(c, RDC_ERR_STATE, "solution field not set");
+  if (n_elem < 0) n_elem = c->prep.n_elem;
+  if (n_elem > c->prep.n_elem) return fail(c, RDC_ERR_INVALID, "n_elem exceeds the mesh");
+  int rc = set_device(c);
+  if (rc) return rc;
+  int64_t grid = (n_elem + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  if ((rc = dev_alloc(c, c->wg_max, (size_t)grid * 2 * sizeof(double)))) return rc;
+  const MeshDev m = mesh_view(c);
+  if (c->prep.nen == 4)
+    hipLaunchKernelGGL((k_ripf_volumes<4>), dim3((unsigned)grid), dim3(256), 0, c->stream, m, n_elem,
+                       (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p, *r, (double*)c->wg_max.p);
+  else
+    hipLaunchKernelGGL((k_ripf_volumes<8>), dim3((unsigned)grid), dim3(256), 0, c->stream, m, n_elem,
+                       (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p, *r, (double*)c->wg_max.p);
+  RDC_HIP(c, hipGetLastError());
+  std::vector<double> h((size_t)grid * 2);
+  RDC_HIP(c, hipMemcpyAsync(h.data(), c->wg_max.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  for (int x = 0; x < 2; x++) {
+    double s = 0.0;
+    for (int64_t g = 0; g < grid; g++) s += h[(size_t)g * 2 + x];
+    out2[x] = s;
+  }
+  return RDC_OK;
+}
+
+int rdc_adpm_parcellation_integrals(rdc_ctx* c, const rdc_adpm_ranges* r, const int32_t* elem_subdomain,
+                                    const int32_t* ids, int32_t n_ids, int64_t n_elem, double* out,
+                                    int64_t* last_elem) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!r || !elem_subdomain || !ids || !out) return fail(c, RDC_ERR_INVALID, "null argument");
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (c->prep.nvar != 3) return fail(c, RDC_ERR_INVALID, "ADPM parcellation integrals need nvar=3");
+  if (!c->field[RDC_FIELD_OLD_SOLUTION].p) return fail(c, RDC_ERR_STATE, "solution field not set");
+  if (n_ids <= 0 || n_ids > 2048) return fail(c, RDC_ERR_INVALID, "n_ids must be in [1, 2048]");
+  for (int32_t i = 1; i < n_ids; i++)
+    if (ids[i] <= ids[i - 1]) return fail(c, RDC_ERR_INVALID, "parcellation ids must be strictly ascending");
+  if (n_elem < 0) n_elem = c->prep.n_elem;
+  if (n_elem > c->prep.n_elem) return fail(c, RDC_ERR_INVALID, "n_elem exceeds the mesh");
+  int rc = set_device(c);
+  if (rc) return rc;
+  // region slot of every element; the last element of each region carries bit 30
+  std::vector<int32_t> slot((size_t)(n_elem > 0 ? n_elem : 1), -1);
+  std::vector<int64_t> last((size_t)n_ids, -1);
+  for (int64_t e = 0; e < n_elem; e++) {
+    const int32_t* it = std::lower_bound(ids, ids + n_ids, elem_subdomain[e]);
+    if (it == ids + n_ids || *it != elem_subdomain[e]) continue;
+    slot[(size_t)e] = (int32_t)(it - ids);
+    last[(size_t)(it - ids)] = e;
+  }
+  for (int32_t i = 0; i < n_ids; i++)
+    if (last[(size_t)i] >= 0) slot[(size_t)last[(size_t)i]] |= 0x40000000;
+  int64_t grid = (n_elem + 255) / 256;
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  const size_t n_part = (size_t)grid * 2 * n_ids;
+  if ((rc = dev_alloc(c, c->wg_max, (n_part + 2 * (size_t)n_ids) * sizeof(double)))) return rc;
+  if ((rc = dev_upload(c, c->adpm_slot, slot))) return rc;
+  double* part = (double*)c->wg_max.p;
+  double* conc = part + n_part;
+  RDC_HIP(c, hipMemsetAsync(conc, 0, 2 * (size_t)n_ids * sizeof(double), c->stream));
+  const MeshDev m = mesh_view(c);
+  const size_t lds = 2 * (size_t)n_ids * sizeof(double);
+  if (c->prep.nen == 4)
+    hipLaunchKernelGGL((k_adpm_parcellation<4>), dim3((unsigned)grid), dim3(256), lds, c->stream, m, n_elem,
+                       (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p, *r, (const int32_t*)c->adpm_slot.p, (int)n_ids, part, conc);
+  else
+    hipLaunchKernelGGL((k_adpm_parcellation<8>), dim3((unsigned)grid), dim3(256), lds, c->stream, m, n_elem,
+                       (const double*)c->field[RDC_FIELD_OLD_SOLUTION].p, *r, (const int32_t*)c->adpm_slot.p, (int)n_ids, part, conc);
+  RDC_HIP(c, hipGetLastError());
+  std::vector<double> h(n_part + 2 * (size_t)n_ids);
+  RDC_HIP(c, hipMemcpyAsync(h.data(), c->wg_max.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  for (int32_t i = 0; i < n_ids; i++) {
+    double sa = 0.0, st = 0.0;
+    for (int64_t g = 0; g < grid; g++) {
+      sa += h[(size_t)g * 2 * n_ids + 2 * i];
+      st += h[(size_t)g * 2 * n_ids + 2 * i + 1];
+    }
+    out[4 * i] = h[n_part + 2 * i];
+    out[4 * i + 1] = h[n_part + 2 * i + 1];
+    out[4 * i + 2] = sa;
+    out[4 * i + 3] = st;
+    if (last_elem) last_elem[i] = last[(size_t)i];
   }
   return RDC_OK;
 }

@@ -375,6 +375,92 @@ k_pihna_volumes(const MeshDev m, int64_t n_elem, const double* __restrict__ u, c
   if (threadIdx.x < 4) part[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// RIPF save_solution volume sums (src/ripf.C:812-858): per-workgroup partial sums -> part[blockIdx.x][2]
+template <int NEN>
+static __global__ void __launch_bounds__(256)
+k_ripf_volumes(const MeshDev m, int64_t n_elem, const double* __restrict__ u, const rdc_ripf_ranges r,
+               double* __restrict__ part) {
+  __shared__ double red[2][256];
+  double acc[2] = {0.0, 0.0};
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * 256) {
+    double X[NEN][3];
+    bool ok[2] = {true, true};
+#pragma unroll
+    for (int i = 0; i < NEN; i++) {
+      const int64_t n = m.conn[e * NEN + i];
+#pragma unroll
+      for (int d = 0; d < 3; d++) X[i][d] = m.xyz[3 * n + d];
+      const double HU = u[3 * n], cc = u[3 * n + 1], fb = u[3 * n + 2];
+      ok[0] = ok[0] && (HU >= r.cc_HU_min && HU <= r.cc_HU_max && cc >= r.cc_min);
+      ok[1] = ok[1] && (HU >= r.fb_HU_min && HU <= r.fb_HU_max && fb >= r.fb_min);
+    }
+    double vol = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < Ref<NEN>::NQP; q++) {
+      double N[NEN], G[NEN][3], W;
+      fe_point<NEN>(X, q, N, G, W);
+      vol += W;
+    }
+    acc[0] += ok[0] ? vol : 0.0;
+    acc[1] += ok[1] ? vol : 0.0;
+  }
+  red[0][threadIdx.x] = acc[0];
+  red[1][threadIdx.x] = acc[1];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) part[blockIdx.x * 2 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// ADPM save_solution (src/adpm.C:747-813).  slot[e] = index of the element's subdomain in the parcellation (-1: not
+// listed), bit 30 set on the last element of its region: that one writes the region's concentrations (upstream
+// assigns, so the last element wins).  Thresholded volumes: LDS sums per region -> part[blockIdx.x][n_ids][2].
+template <int NEN>
+static __global__ void __launch_bounds__(256)
+k_adpm_parcellation(const MeshDev m, int64_t n_elem, const double* __restrict__ u, const rdc_adpm_ranges r,
+                    const int32_t* __restrict__ slot, int n_ids, double* __restrict__ part, double* __restrict__ conc) {
+  extern __shared__ double sums[];  // [n_ids][2]
+  for (int i = threadIdx.x; i < 2 * n_ids; i += 256) sums[i] = 0.0;
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_elem; e += (int64_t)gridDim.x * 256) {
+    const int32_t sf = slot[e];
+    if (sf < 0) continue;
+    const int sl = sf & 0x3fffffff;
+    double X[NEN][3], Ab[NEN], Ta[NEN];
+    bool okA = true, okT = true;
+#pragma unroll
+    for (int i = 0; i < NEN; i++) {
+      const int64_t n = m.conn[e * NEN + i];
+#pragma unroll
+      for (int d = 0; d < 3; d++) X[i][d] = m.xyz[3 * n + d];
+      Ab[i] = u[3 * n + 1];
+      Ta[i] = u[3 * n + 2];
+      okA = okA && (Ab[i] >= r.A_b_min && Ab[i] <= r.A_b_max);
+      okT = okT && (Ta[i] >= r.Tau_min && Ta[i] <= r.Tau_max);
+    }
+    double vol = 0.0, avA = 0.0, avT = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < Ref<NEN>::NQP; q++) {
+      double N[NEN], G[NEN][3], W;
+      fe_point<NEN>(X, q, N, G, W);
+      double a = 0.0, t = 0.0;
+#pragma unroll
+      for (int l = 0; l < NEN; l++) { a += N[l] * Ab[l]; t += N[l] * Ta[l]; }
+      vol += W; avA += W * a; avT += W * t;
+    }
+    if (okA) atomicAdd(&sums[2 * sl], vol);
+    if (okT) atomicAdd(&sums[2 * sl + 1], vol);
+    if (sf & 0x40000000) { conc[2 * sl] = avA / vol; conc[2 * sl + 1] = avT / vol; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * n_ids; i += 256) part[(size_t)blockIdx.x * 2 * n_ids + i] = sums[i];
+}
+
 // RIPF check_solution (src/ripf.C:675-775): clamp, time-derivative system, fractionation schedule, prev := unclamped,
 // aux record of the next assembly; per-workgroup maxima of the total dose go to wg_max[blockIdx.x].
 static __global__ void __launch_bounds__(256)

@@ -24,6 +24,7 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <ostream>
 #include <string>
 #include <variant>
 #include <vector>
@@ -438,6 +439,40 @@ inline void check_solution(EquationSystems& es, const std::string& system_name) 
   check(c, rdc_clamp_nonnegative(c, RDC_FIELD_OLD_SOLUTION), "rdc_clamp_nonnegative");
   check(c, rdc_field_download(c, RDC_FIELD_OLD_SOLUTION, system.solution.raw().data(), system.solution.size()), "solution");
   system.update();
+}
+
+// save_solution of PIHNA (src/pihna.C:842-976): one CSV line per call -- time, number of dofs and the four
+// thresholded element-volume sums, which the device computes from the current solution; header at time 0
+inline void save_solution_pihna(std::ostream& csv, EquationSystems& es) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>("PIHNA");
+  const Parameters& P = es.parameters;
+  rdc_pihna_ranges r;
+  r.active_tumor_min = detail::getR(P, "range/active_tumor/min"); r.active_tumor_max = detail::getR(P, "range/active_tumor/max");
+  r.necrotic_min = detail::getR(P, "range/necrotic/min"); r.necrotic_max = detail::getR(P, "range/necrotic/max");
+  r.vascularity_min = detail::getR(P, "range/vascularity/min"); r.vascularity_max = detail::getR(P, "range/vascularity/max");
+  r.total_cell_min = detail::getR(P, "range/total_cell/min"); r.total_cell_max = detail::getR(P, "range/total_cell/max");
+  r.cells_max_capacity = detail::getR(P, "cells_max_capacity");
+  rdc_ctx* c = es.context("PIHNA", 5);
+  double v[4];
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.solution.raw().data(), system.solution.size()), "solution");
+  check(c, rdc_pihna_volume_integrals(c, &r, -1, v), "rdc_pihna_volume_integrals");
+  if (0.0 == system.time)
+    csv << "\"TIME\",\"DEGREES_OF_FREEDOM\",\"ACTIVE_TUMOR_VOLUME\",\"NECROTIC_VOLUME\",\"VASCULARITY_VOLUME\",\"TOTAL_CELL_VOLUME\"" << std::endl;
+  csv << system.time << ',' << (system.n_vars() * es.get_mesh().n_nodes()) << ',' << v[0] << ',' << v[1] << ',' << v[2] << ',' << v[3] << std::endl;
+}
+
+// save_solution of RIPF (src/ripf.C:777-866): time, tumour volume, fibrosis volume (upstream writes no header)
+inline void save_solution_ripf(std::ostream& csv, EquationSystems& es) {
+  auto& system = es.get_system<TransientLinearImplicitSystem>("RIPF");
+  const Parameters& P = es.parameters;
+  rdc_ripf_ranges r;
+  r.cc_HU_min = detail::getR(P, "range_cc/HU/min"); r.cc_HU_max = detail::getR(P, "range_cc/HU/max"); r.cc_min = detail::getR(P, "range_cc/min");
+  r.fb_HU_min = detail::getR(P, "range_fb/HU/min"); r.fb_HU_max = detail::getR(P, "range_fb/HU/max"); r.fb_min = detail::getR(P, "range_fb/min");
+  rdc_ctx* c = es.context("RIPF", 3);
+  double v[2];
+  check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.solution.raw().data(), system.solution.size()), "solution");
+  check(c, rdc_ripf_volume_integrals(c, &r, -1, v), "rdc_ripf_volume_integrals");
+  csv << system.time << ',' << v[0] << ',' << v[1] << std::endl;
 }
 
 }  // namespace host

@@ -69,6 +69,16 @@ class PihnaRanges(C.Structure):
                                   "vascularity_max", "total_cell_min", "total_cell_max", "cells_max_capacity")]
 
 
+class RipfRanges(C.Structure):
+    """rdc_ripf_ranges: the "range_cc/*", "range_fb/*" keys of save_solution, src/ripf.C:790-795."""
+    _fields_ = [(f, _D) for f in ("cc_HU_min", "cc_HU_max", "cc_min", "fb_HU_min", "fb_HU_max", "fb_min")]
+
+
+class AdpmRanges(C.Structure):
+    """rdc_adpm_ranges: the "range/A_b/*", "range/Tau/*" keys of save_solution, src/adpm.C:702-705."""
+    _fields_ = [(f, _D) for f in ("A_b_min", "A_b_max", "Tau_min", "Tau_max")]
+
+
 class RipfCheckParams(C.Structure):
     """rdc_ripf_check_params: what check_solution reads, src/ripf.C:697-703."""
     _fields_ = [("time_step", _D), ("HU_min", _D), ("HU_max", _D), ("RT_broad_fractions", C.c_int32),

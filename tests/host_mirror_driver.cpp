@@ -110,6 +110,17 @@ int main(int argc, char** argv) {
       if (model->solution.raw() != expect) throw std::runtime_error("check_solution: clamp mismatch");
       model->solution.raw() = keep;
     }
+    // save_solution(): the CSV line of the model (src/pihna.C:59, src/ripf.C:63), volume sums computed on the device
+    if (model_name == "pihna" && es.parameters.have_parameter<Real>("range/active_tumor/min")) {
+      std::ofstream csv(dir + "/out.csv");
+      csv.precision(17);
+      save_solution_pihna(csv, es);
+    }
+    if (model_name == "ripf" && es.parameters.have_parameter<Real>("range_cc/min")) {
+      std::ofstream csv(dir + "/out.csv");
+      csv.precision(17);
+      save_solution_ripf(csv, es);
+    }
     write_raw(dir + "/val.bin", model->matrix->val);
     write_raw(dir + "/rhs.bin", model->rhs->raw());
     write_raw(dir + "/row_ptr.bin", model->matrix->row_ptr);

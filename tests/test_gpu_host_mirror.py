@@ -85,9 +85,31 @@ def test_callback_through_host_mirror(oracle, driver, tmp_path, model, nen):
     if model == "hcc":
         from rdcfes_amd.params import HCC_DEFAULTS
         d = {**HCC_DEFAULTS, **d}
+    if model == "pihna":
+        d = {**d, "range/active_tumor/min": 100.0, "range/active_tumor/max": 1e9, "range/necrotic/min": 50.0, "range/necrotic/max": 1e9,
+             "range/vascularity/min": 0.0, "range/vascularity/max": 7000.0, "range/total_cell/min": 0.031, "range/total_cell/max": 1.0}
+    if model == "ripf":
+        d = {**d, "range_cc/HU/min": -1e9, "range_cc/HU/max": 1e9, "range_cc/min": float(np.median(u[:, 1])),
+             "range_fb/HU/min": -1e9, "range_fb/HU/max": 1e9, "range_fb/min": float(np.median(u[:, 2]))}
     _write_case(tmp_path, conn, xyz, u, d, extra)
     r = subprocess.run([str(driver), str(tmp_path), model, str(nen)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    if model == "pihna":     # save_solution: header + one line (time 0), volumes from the device
+        from rdcfes_amd import PihnaRanges
+        head, line = (tmp_path / "out.csv").read_text().splitlines()
+        assert head.startswith('"TIME","DEGREES_OF_FREEDOM","ACTIVE_TUMOR_VOLUME"')
+        f = [float(x) for x in line.split(",")]
+        v0 = oracle.pihna_volume_integrals(nen, conn, xyz, u, PihnaRanges(100.0, 1e9, 50.0, 1e9, 0.0, 7000.0, 0.031, 1.0, d["cells_max_capacity"]))
+        assert f[0] == 0.0 and f[1] == 5 * xyz.shape[0]
+        np.testing.assert_allclose(f[2:], v0, rtol=1e-12, atol=1e-15)
+        assert 0.0 < v0[0] < 1.0
+    if model == "ripf":
+        from rdcfes_amd import RipfRanges
+        (line,) = (tmp_path / "out.csv").read_text().splitlines()
+        f = [float(x) for x in line.split(",")]
+        v0 = oracle.ripf_volume_integrals(nen, conn, xyz, u, RipfRanges(-1e9, 1e9, d["range_cc/min"], -1e9, 1e9, d["range_fb/min"]))
+        np.testing.assert_allclose(f[1:], v0, rtol=1e-12, atol=1e-15)
+        assert np.all(v0 > 0.0) and np.all(v0 < 1.0)
     val = np.fromfile(tmp_path / "val.bin")
     rhs = np.fromfile(tmp_path / "rhs.bin")
     rp = np.fromfile(tmp_path / "row_ptr.bin", dtype=np.int64)

@@ -74,3 +74,100 @@ def test_gpu_volume_integrals(oracle, nen):
         vh = ctx.pihna_volume_integrals(_ranges(), half)
     np.testing.assert_allclose(v, v0, rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(vh, v0h, rtol=1e-12, atol=1e-15)
+
+
+# ---- RIPF and ADPM CSV reductions (src/ripf.C:777-866, src/adpm.C:690-829) ---------------------------------------
+def _ripf_state(xyz):
+    rng = np.random.default_rng(11)
+    r = np.linalg.norm(xyz - 0.5, axis=1)
+    u = np.empty((xyz.shape[0], 3))
+    u[:, 0] = -900.0 + 1200.0 * np.exp(-6.0 * r * r) + 20.0 * rng.standard_normal(xyz.shape[0])   # HU
+    u[:, 1] = 0.8 * np.exp(-10.0 * r * r)                                                           # cc
+    u[:, 2] = 0.5 * np.exp(-4.0 * (r - 0.3) ** 2)                                                   # fb
+    return u
+
+
+def _ripf_ranges():
+    from rdcfes_amd import RipfRanges
+    return RipfRanges(-500.0, 400.0, 0.2, -800.0, 300.0, 0.25)
+
+
+def _adpm_case(nen, n):
+    conn, xyz = synth.kuhn_tet_mesh(n, jitter=0.1, order="random") if nen == 4 else synth.hex_mesh(n, jitter=0.1, order="random")
+    rng = np.random.default_rng(5)
+    u = np.abs(rng.standard_normal((xyz.shape[0], 3))) * np.array([1.0, 0.4, 0.2]) + 0.3 * xyz
+    cen = xyz[conn.astype(np.int64)].mean(axis=1)
+    sub = (1001 + 7 * (np.floor(cen[:, 0] * 3).astype(np.int32) + 3 * np.floor(cen[:, 1] * 2).astype(np.int32))).astype(np.int32)
+    ids = np.unique(np.concatenate([sub, [5000]])).astype(np.int32)      # one listed region has no element
+    return conn, xyz, u, sub, ids
+
+
+@pytest.mark.parametrize("nen", [4, 8])
+def test_oracle_ripf_and_adpm_reductions(oracle, nen):
+    from rdcfes_amd import AdpmRanges, RipfRanges
+    conn, xyz = synth.kuhn_tet_mesh(5, jitter=0.1) if nen == 4 else synth.hex_mesh(5, jitter=0.1)
+    u = _ripf_state(xyz)
+    every = RipfRanges(-1e300, 1e300, -1e300, -1e300, 1e300, -1e300)
+    np.testing.assert_allclose(oracle.ripf_volume_integrals(nen, conn, xyz, u, every), 1.0, rtol=1e-12)
+    assert np.all(oracle.ripf_volume_integrals(nen, conn, xyz, u, RipfRanges(1.0, -1.0, 0.0, 1.0, -1.0, 0.0)) == 0.0)
+    v = oracle.ripf_volume_integrals(nen, conn, xyz, u, _ripf_ranges())
+    assert np.all(v > 0.0) and np.all(v < 1.0)
+    # ADPM: a linear field is reproduced by the element average; region volumes add up to the cube; the last element wins
+    conn, xyz, u, sub, ids = _adpm_case(nen, 4)
+    u[:, 1] = 2.0 + xyz[:, 0] - 3.0 * xyz[:, 2]
+    out = oracle.adpm_parcellation_integrals(nen, conn, xyz, u, AdpmRanges(-1e300, 1e300, -1e300, 1e300), sub, ids)
+    np.testing.assert_allclose(out[:, 2].sum(), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(out[:, 2], out[:, 3], rtol=0, atol=0)
+    assert np.all(out[ids == 5000] == 0.0)
+    for i, ID in enumerate(ids[:-1]):
+        e = np.flatnonzero(sub == ID)[-1]
+        if nen == 4:   # volume-weighted centroid of a tet = mean of its nodes: exact for the linear field
+            cen = xyz[conn[e].astype(np.int64)].mean(axis=0)
+            np.testing.assert_allclose(out[i, 0], 2.0 + cen[0] - 3.0 * cen[2], rtol=1e-12)
+        lo, hi = u[conn[e].astype(np.int64), 1].min(), u[conn[e].astype(np.int64), 1].max()
+        assert lo <= out[i, 0] <= hi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nen", [4, 8])
+def test_gpu_ripf_volume_integrals(oracle, nen):
+    from rdcfes_amd import AssemblyContext, FIELD_OLD_SOLUTION
+    conn, xyz = synth.kuhn_tet_mesh(9, jitter=0.1, order="random") if nen == 4 else synth.hex_mesh(8, jitter=0.1, order="random")
+    u = _ripf_state(xyz)
+    half = conn.shape[0] // 2
+    v0 = oracle.ripf_volume_integrals(nen, conn, xyz, u, _ripf_ranges())
+    v0h = oracle.ripf_volume_integrals(nen, conn, xyz, u, _ripf_ranges(), n_elem=half)
+    assert np.all(v0 > 0.0)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(nen, conn, xyz, 3)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        v = ctx.ripf_volume_integrals(_ripf_ranges())
+        vh = ctx.ripf_volume_integrals(_ripf_ranges(), half)
+    np.testing.assert_allclose(v, v0, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(vh, v0h, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nen", [4, 8])
+def test_gpu_adpm_parcellation_integrals(oracle, nen):
+    from rdcfes_amd import AdpmRanges, AssemblyContext, FIELD_OLD_SOLUTION, RdcError
+    conn, xyz, u, sub, ids = _adpm_case(nen, 9 if nen == 4 else 8)
+    rg = AdpmRanges(0.1, 0.9, 0.05, 0.45)
+    half = conn.shape[0] // 2
+    o0 = oracle.adpm_parcellation_integrals(nen, conn, xyz, u, rg, sub, ids)
+    o0h = oracle.adpm_parcellation_integrals(nen, conn, xyz, u, rg, sub, ids, n_elem=half)
+    assert (o0[:, 2] > 0).sum() >= 3 and (o0[:, 3] > 0).sum() >= 3
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(nen, conn, xyz, 3)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        o, last = ctx.adpm_parcellation_integrals(rg, sub, ids)
+        oh, lasth = ctx.adpm_parcellation_integrals(rg, sub, ids, half)
+        with pytest.raises(RdcError):
+            ctx.adpm_parcellation_integrals(rg, sub, ids[::-1])          # the parcellation is an ordered set
+    np.testing.assert_allclose(o, o0, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(oh, o0h, rtol=1e-12, atol=1e-15)
+    for i, ID in enumerate(ids):
+        w = np.flatnonzero(sub == ID)
+        assert last[i] == (w[-1] if w.size else -1)
+        wh = w[w < half]
+        assert lasth[i] == (wh[-1] if wh.size else -1)
