@@ -79,6 +79,12 @@ RDC_HD void rd_point_setup(const typename M::K& k, const double (&X)[NEN][3], co
   for (int g = 0; g < NG; g++) P.gi[g] = GF[g][0] * P.Gi[0] + GF[g][1] * P.Gi[1] + GF[g][2] * P.Gi[2];
 }
 
+// The accumulation below is written per structurally non-zero coefficient (M::hasA / hasB / hasD / hasRG, the masks of
+// the factored TET4 kernels): without fast-math the compiler may not drop `0.0 * x`, so the plain triple product
+// over all NV x NV blocks costs 27 multiply-adds per column on a three-unknown model of which HCC needs 11.  The
+// quadrature weight is folded into the row-node factors once per point (W*phi_i, W*grad phi_i, W*beta_ab), which
+// leaves one FMA per non-zero coefficient and column.
+
 // equation row A only (everything else of coef() is dead code): for element types / models whose full NV x NV x NEN
 // accumulator does not fit the register file
 template <class M, int NEN, int A>
@@ -86,18 +92,33 @@ RDC_HD void rd_point_accum_row(const RowPoint<M, NEN>& P, double (&acc)[M::NV][N
   constexpr int NV = M::NV, NG = M::NG;
   double r = P.c.R[A] * P.Ni;
 #pragma unroll
-  for (int g = 0; g < NG; g++) r += P.c.RG[A][g] * P.gi[g];
+  for (int g = 0; g < NG; g++)
+    if (M::hasRG(A, g)) r += P.c.RG[A][g] * P.gi[g];
   fe += P.W * r;
+  const double wNi = P.W * P.Ni;
+  const double wG[3] = {P.W * P.Gi[0], P.W * P.Gi[1], P.W * P.Gi[2]};
+  double bgw[NV];
+  bool anyB[NV];
+#pragma unroll
+  for (int b = 0; b < NV; b++) {
+    double bg = 0.0;
+    anyB[b] = false;
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+      if (M::hasB(A, b, g)) { bg += P.c.B[A][b][g] * P.gi[g]; anyB[b] = true; }
+    bgw[b] = P.W * bg;
+  }
 #pragma unroll
   for (int j = 0; j < NEN; j++) {
-    const double pp = P.N[j] * P.Ni;
-    const double dd = P.G[j][0] * P.Gi[0] + P.G[j][1] * P.Gi[1] + P.G[j][2] * P.Gi[2];
+    const double pp = P.N[j] * wNi;
+    const double dd = P.G[j][0] * wG[0] + P.G[j][1] * wG[1] + P.G[j][2] * wG[2];
 #pragma unroll
     for (int b = 0; b < NV; b++) {
-      double bg = 0.0;
-#pragma unroll
-      for (int g = 0; g < NG; g++) bg += P.c.B[A][b][g] * P.gi[g];
-      acc[b][j] += P.W * (P.c.A[A][b] * pp + P.N[j] * bg + P.c.D[A][b] * dd);
+      double v = acc[b][j];
+      if (M::hasA(A, b)) v += P.c.A[A][b] * pp;
+      if (anyB[b]) v += bgw[b] * P.N[j];
+      if (M::hasD(A, b)) v += P.c.D[A][b] * dd;
+      acc[b][j] = v;
     }
   }
 }
@@ -114,21 +135,38 @@ RDC_HD void rd_row_point(const typename M::K& k, const double (&X)[NEN][3], cons
   for (int a = 0; a < NV; a++) {
     double r = P.c.R[a] * P.Ni;
 #pragma unroll
-    for (int g = 0; g < NG; g++) r += P.c.RG[a][g] * P.gi[g];
+    for (int g = 0; g < NG; g++)
+      if (M::hasRG(a, g)) r += P.c.RG[a][g] * P.gi[g];
     fe[a] += P.W * r;
   }
+  const double wNi = P.W * P.Ni;
+  const double wG[3] = {P.W * P.Gi[0], P.W * P.Gi[1], P.W * P.Gi[2]};
+  double bgw[NV][NV];
+  bool anyB[NV][NV];
+#pragma unroll
+  for (int a = 0; a < NV; a++)
+#pragma unroll
+    for (int b = 0; b < NV; b++) {
+      double bg = 0.0;
+      anyB[a][b] = false;
+#pragma unroll
+      for (int g = 0; g < NG; g++)
+        if (M::hasB(a, b, g)) { bg += P.c.B[a][b][g] * P.gi[g]; anyB[a][b] = true; }
+      bgw[a][b] = P.W * bg;
+    }
 #pragma unroll
   for (int j = 0; j < NEN; j++) {
-    const double pp = P.N[j] * P.Ni;
-    const double dd = P.G[j][0] * P.Gi[0] + P.G[j][1] * P.Gi[1] + P.G[j][2] * P.Gi[2];
+    const double pp = P.N[j] * wNi;
+    const double dd = P.G[j][0] * wG[0] + P.G[j][1] * wG[1] + P.G[j][2] * wG[2];
 #pragma unroll
     for (int a = 0; a < NV; a++)
 #pragma unroll
       for (int b = 0; b < NV; b++) {
-        double bg = 0.0;
-#pragma unroll
-        for (int g = 0; g < NG; g++) bg += P.c.B[a][b][g] * P.gi[g];
-        acc[a][b][j] += P.W * (P.c.A[a][b] * pp + P.N[j] * bg + P.c.D[a][b] * dd);
+        double v = acc[a][b][j];
+        if (M::hasA(a, b)) v += P.c.A[a][b] * pp;
+        if (anyB[a][b]) v += bgw[a][b] * P.N[j];
+        if (M::hasD(a, b)) v += P.c.D[a][b] * dd;
+        acc[a][b][j] = v;
       }
   }
 }
