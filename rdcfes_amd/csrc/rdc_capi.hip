@@ -7,6 +7,7 @@
 #include <new>
 
 #include "rdc_internal.h"
+#include "rdc_tet4_pihna_moments.h"
 #include "rdc_solid.h"
 
 using namespace rdc;
@@ -38,6 +39,8 @@ struct rdc_ctx {
   int opt_special = 1;  // allow parameter-sparsity kernel variants
   int opt_part = 0;            // 0 = whole mesh, 1 = workgroups of interior nodes only, 2 = the remaining workgroups
   int64_t opt_interior = -1;   // owned nodes [0, opt_interior) have no ghost node in any of their elements
+  int opt_stagger = 0;
+  int opt_moments = 1;  // PIHNA (cell transport off) TET4: moment form of the rows
   int opt_slim = 0;     // PIHNA: slim per-point state (re-derived per equation row); with occupancy=3 three waves per SIMD
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
@@ -195,6 +198,7 @@ template <>
 hipError_t launch_specialised<Pihna, rdc_pihna_params>(const LaunchArgs& a, const Pihna::K& k, const rdc_pihna_params& p) {
   if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && PihnaNoCellTransport::applies(p)) {
     if (a.opt_slim && a.exp_mode == 3) return launch_tet4_fast<PihnaNoCellTransportSlim>(a, k);
+    if (a.opt_moments) return launch_tet4_fast<PihnaNoCellTransportMoments>(a, k);  // same sums, moment form
     return launch_tet4_fast<PihnaNoCellTransport>(a, k);
   }
   return launch_rd<Pihna>(a, k);
@@ -237,6 +241,8 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_kernel = c->opt_kernel;
   a.opt_special = c->opt_special;
   a.opt_slim = c->opt_slim;
+  a.opt_moments = c->opt_moments;
+  a.opt_stagger = c->opt_stagger;
   a.opt_xcd = c->opt_xcd;
   a.opt_grid = c->opt_grid;
   a.opt_pf = c->opt_pf;
@@ -395,6 +401,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   }
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
   else if (!std::strcmp(key, "slim")) c->opt_slim = value;
+  else if (!std::strcmp(key, "stagger")) c->opt_stagger = value;  // k_tet4_rg5: start delay of every CU's second workgroup, in units of 1024 cycles
+  else if (!std::strcmp(key, "moments")) c->opt_moments = value;  // 1 (default): shipped-pattern PIHNA/TET4 rows in moment form (rdc_tet4_pihna_moments.h), 0: coefficient form
   else if (!std::strcmp(key, "interior_nodes")) c->opt_interior = value;  // see rdc_assembly.h (two-part assembly)
   else if (!std::strcmp(key, "part")) {
     if (value < 0 || value > 2) return fail(c, RDC_ERR_INVALID, "part must be 0, 1 or 2");

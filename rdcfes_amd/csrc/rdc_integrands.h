@@ -102,6 +102,8 @@ struct PihnaK {  // src/pihna.C:358-381
   double dif_c, tax_c, dif_h, tax_h, prod_c, c2h, h2c, h2n;
   double dif_v, tax_v, prod_v;
   double sec_c, sec_h, upt, dec;
+  // time-step-weighted rates of the moment form (rdc_tet4_pihna_moments.h): DT2 * rate, formed once on the host
+  double Tn_c, Tn_h, Tn_v, Th2n, Tprod_c, Tc2h, Th2c, Tprod_v, Tdif_v, Tsec_c, Tsec_h, Tupt, Tdec;
 };
 
 struct Pihna {
@@ -146,6 +148,10 @@ struct Pihna {
     k.prod_c = p.produce_c; k.c2h = p.switch_c2h; k.h2c = p.switch_h2c; k.h2n = p.switch_h2n;
     k.dif_v = p.diffuse_v; k.tax_v = p.taxis_v; k.prod_v = p.produce_v;
     k.sec_c = p.secrete_a_c; k.sec_h = p.secrete_a_h; k.upt = p.uptake_a_v; k.dec = p.decay_a;
+    k.Tn_c = k.DT2 * k.nec_c; k.Tn_h = k.DT2 * k.nec_h; k.Tn_v = k.DT2 * k.nec_v; k.Th2n = k.DT2 * k.h2n;
+    k.Tprod_c = k.DT2 * k.prod_c; k.Tc2h = k.DT2 * k.c2h; k.Th2c = k.DT2 * k.h2c; k.Tprod_v = k.DT2 * k.prod_v;
+    k.Tdif_v = k.DT2 * k.dif_v; k.Tsec_c = k.DT2 * k.sec_c; k.Tsec_h = k.DT2 * k.sec_h; k.Tupt = k.DT2 * k.upt;
+    k.Tdec = k.DT2 * k.dec;
     return k;
   }
   static inline double exponent(const K& k) { return k.ek; }

@@ -152,14 +152,24 @@ RDC_HD void tet4_row(const typename M::K& k, const Tet4Pre<M>& P, int a, Sink& s
     }
 }
 
+// How the rows of a pair are formed from the prepared element data.  Default: coefficient form, one equation row at
+// a time (tet4_row).  A model may specialise this (rdc_tet4_pihna_moments.h).
+template <class M>
+struct Tet4Rows {
+  template <class Sink>
+  RDC_HD static void run(const typename M::K& k, const Tet4Pre<M>& P, Sink& sink) {
+#pragma unroll
+    for (int a = 0; a < M::NV; a++) tet4_row<M>(k, P, a, sink);
+  }
+};
+
 // all rows of the pair
 template <class M, int EXP_MODE, class Sink>
 RDC_HD void tet4_row0(const typename M::K& k, const double (&X)[4][3], const double (&U)[4][M::NV],
                       const double (&AX)[4][M::NAUX > 0 ? M::NAUX : 1], Sink& sink, const double* ED = nullptr) {
   Tet4Pre<M> P;
   tet4_prepare<M, EXP_MODE>(k, X, U, AX, P, ED);
-#pragma unroll
-  for (int a = 0; a < M::NV; a++) tet4_row<M>(k, P, a, sink);
+  Tet4Rows<M>::run(k, P, sink);
 }
 
 }  // namespace rdc

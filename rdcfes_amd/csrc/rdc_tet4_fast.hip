@@ -8,6 +8,7 @@
 // Replaces the element loop src/pihna.C:383-756 (src/ripf.C:410-671, src/coupled_hcc.C:463-646).
 #include "rdc_internal.h"
 #include "rdc_tet4_fast.h"
+#include "rdc_tet4_pihna_moments.h"
 
 #include <type_traits>
 
@@ -267,7 +268,8 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
            const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
            double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
            long long* __restrict__ stamps, const int pf_dist, const int xcd_remap,
-           const uint32_t* __restrict__ pair_eid, const double* __restrict__ elem, const int wg_begin) {
+           const uint32_t* __restrict__ pair_eid, const double* __restrict__ elem, const int wg_begin,
+           const int stagger) {
   constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
   constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
@@ -276,6 +278,15 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   long long ts[6], tx[3] = {0, 0, 0};
   if (STAMP) ts[0] = __builtin_amdgcn_s_memtime();
+  // Diagnostic knob (rdc_set_option "stagger", default 0): delays the SECOND workgroup of every CU (its LDS allocation
+  // does not start at 0) once, in the first dispatch round.  It tests whether the two co-resident workgroups run in
+  // lock-step phases (kernel time = data-movement skeleton + arithmetic); measured: the
+  // offset changes nothing (2.59 ms for 0..24 K cycles), so phase alignment is not what keeps the two from overlapping.
+  if (stagger > 0 && blockIdx.x < 2048u) {
+    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6) ;  // HW_REG_LDS_ALLOC.LDS_BASE (bits 7:0)
+    if (lds_base != 0)
+      for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
+  }
   int w = blockIdx.x;
   if (xcd_remap) {  // contiguous range of work items per XCD (see k_tet4_rg3); speed only
     const int q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
@@ -334,7 +345,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   if (STAMP) tx[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();                                   // ... and so has everybody else's
   if (STAMP) ts[1] = __builtin_amdgcn_s_memtime();
-  if (pl != 0xFFFFFFFFu) {
+  if (pl != 0xFFFFFFFFu && !(ABL >= 3 && ABL <= 5)) {  // diagnostic builds 3..5: no compute phase
     double X[4][3], U[4][NV], AX[4][M::NAUX > 0 ? M::NAUX : 1];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -379,6 +390,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   if (STAMP) ts[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
   if (STAMP) ts[3] = __builtin_amdgcn_s_memtime();
+  if (!(ABL == 4 || ABL == 5))  // diagnostic builds: no fold
   for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
     const int v = x / d.nnodes, n = x - v * d.nnodes;
     const double2* src = reinterpret_cast<const double2*>(lds + dbase + v * ns + n * NC);  // NC is even
@@ -401,6 +413,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
     const int npair = (nval - sh) >> 1;
     const v2d_t* src = reinterpret_cast<const v2d_t*>(lds + 2 * sh);
     v2d_t* dst = reinterpret_cast<v2d_t*>(out + sh);
+    if (!(ABL == 5 || ABL == 6))  // diagnostic builds: no store phase
     for (int x = threadIdx.x; x < npair; x += BLOCK) __builtin_nontemporal_store(src[x], dst + x);
     if (sh && threadIdx.x == 0) __builtin_nontemporal_store(sl[0], out);
     if (((nval - sh) & 1) && threadIdx.x == 64) __builtin_nontemporal_store(sl[nval - 1], out + nval - 1);
@@ -783,25 +796,30 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
 #define RDC_RG5(MINW, ST)                                                                                          \
   hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, MINW, ST>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,     \
                      a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
-                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin)
-    if constexpr (std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) {
+                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin, a.opt_stagger)
+    if constexpr ((std::is_same<M, PihnaNoCellTransport>::value || std::is_same<M, PihnaNoCellTransportMoments>::value) && EXP_MODE == 3) {
       // diagnostic builds (timing only, results are wrong): LDS atomics replaced by plain stores / removed
-      if (a.opt_ablate == 1 || a.opt_ablate == 2) {
-        if (a.opt_ablate == 1)
-          hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 1>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,
-                             a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs,
-                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin);
-        else
-          hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, 2>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,
-                             a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs,
-                             nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin);
+      if (a.opt_ablate >= 1 && a.opt_ablate <= 6) {
+#define RDC_ABL(X)                                                                                                        \
+  hipLaunchKernelGGL((k_tet4_rg5<M, EXP_MODE, BLOCK, 2, false, X>), dim3(wg_count), dim3(BLOCK), lds_bytes, a.stream,      \
+                     a.rg2.desc, a.rg2.pair_loc, a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, \
+                     nl, acc_doubles, a.stamps, a.opt_pf, a.opt_xcd, a.rg2.pair_eid, a.elem, wg_begin, a.opt_stagger)
+        switch (a.opt_ablate) {
+          case 1: RDC_ABL(1); break;   // plain LDS stores instead of atomics
+          case 2: RDC_ABL(2); break;   // no LDS accumulation traffic
+          case 3: RDC_ABL(3); break;   // no compute phase
+          case 4: RDC_ABL(4); break;   // no compute, no fold
+          case 5: RDC_ABL(5); break;   // loads + zero + barriers only
+          default: RDC_ABL(6); break;  // everything but the store phase
+        }
+#undef RDC_ABL
         return hipGetLastError();
       }
     }
-    if constexpr (std::is_same<M, PihnaNoCellTransportSlim>::value) {
+    if constexpr (std::is_same<M, PihnaNoCellTransportSlim>::value || std::is_same<M, PihnaNoCellTransportMoments>::value) {
       if (a.opt_occ == 3) { RDC_RG5(3, false); return hipGetLastError(); }
     }
-    if (a.stamps && std::is_same<M, PihnaNoCellTransport>::value && EXP_MODE == 3) RDC_RG5(2, true);
+    if (a.stamps && (std::is_same<M, PihnaNoCellTransport>::value || std::is_same<M, PihnaNoCellTransportMoments>::value) && EXP_MODE == 3) RDC_RG5(2, true);
     else if (a.opt_occ == 1) RDC_RG5(1, false);
     else RDC_RG5(2, false);
 #undef RDC_RG5
@@ -889,6 +907,7 @@ hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k) {
 template hipError_t launch_tet4_fast<Pihna>(const LaunchArgs&, const Pihna::K&);
 template hipError_t launch_tet4_fast<PihnaNoCellTransport>(const LaunchArgs&, const PihnaNoCellTransport::K&);
 template hipError_t launch_tet4_fast<PihnaNoCellTransportSlim>(const LaunchArgs&, const PihnaNoCellTransportSlim::K&);
+template hipError_t launch_tet4_fast<PihnaNoCellTransportMoments>(const LaunchArgs&, const PihnaNoCellTransportMoments::K&);
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
 template hipError_t launch_tet4_fast<Adpm>(const LaunchArgs&, const Adpm::K&);

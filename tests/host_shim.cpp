@@ -8,6 +8,7 @@
 #include "../rdcfes_amd/csrc/rdc_prep.h"
 #include "../rdcfes_amd/csrc/rdc_row.h"
 #include "../rdcfes_amd/csrc/rdc_tet4_fast.h"
+#include "../rdcfes_amd/csrc/rdc_tet4_pihna_moments.h"
 
 using namespace rdc;
 
@@ -123,6 +124,10 @@ int shim_row(int model, int nen, int fast, int force_general_pow, const void* pa
     case 3:  // PIHNA, cell-transport-off variant: only legal when the parameters allow it
       if (!PihnaNoCellTransport::applies(*(const rdc_pihna_params*)params)) return 3;
       return run<PihnaNoCellTransport>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 6:  // the same in moment form (rdc_tet4_pihna_moments.h); TET4 factored row only
+      if (!PihnaNoCellTransport::applies(*(const rdc_pihna_params*)params)) return 3;
+      if (!fast || nen != 4) return 1;
+      return run<PihnaNoCellTransportMoments>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
   }
   return 2;
 }

@@ -142,3 +142,36 @@ def test_pihna_cell_transport_off_variant(oracle, shim):
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     Xc, uc = np.ascontiguousarray(X), np.ascontiguousarray(u)
     assert shim.shim_row(3, 4, 1, 0, C.byref(pf), dp(Xc), dp(uc), None, 0, dp(acc), dp(fe)) == 3
+
+
+@pytest.mark.parametrize("general_pow", [False, True])
+def test_pihna_moment_form_equals_coefficient_form(oracle, shim, general_pow):
+    """PihnaNoCellTransportMoments (rdc_tet4_pihna_moments.h): the rows assembled from weighted moments of the point
+    functions are the sums of the coefficient form in another association -- against the oracle at the parity
+    tolerance and against the coefficient form much tighter, over states that exercise every branch (crowding
+    saturated / empty, vascular fraction clamped at 0 and 1, vasculature below the diffusion threshold)."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    for seed in range(12):
+        X, u, aux, p = _case(0, 4, 300 + seed, "shipped")
+        if seed % 4 == 1:
+            u[:, 3] = rng.uniform(0.0, 2.0 * p.cells_min_capacity, 4)        # v around the diffusion threshold
+        if seed % 4 == 2:
+            u[:, :4] *= 40.0                                                  # crowding saturated (Te >= 1) at some points
+        if seed % 4 == 3:
+            u[rng.integers(0, 4), 3] = 0.0                                    # Ve clamps
+            u[:, 1:3] *= 1e-3
+        if seed == 8:
+            u[:] = 0.0                                                        # empty element: 0/0 in Ve, as upstream
+        Ke0, Fe0 = oracle.element(0, 4, X, u, p)
+        Ke3, Fe3 = shim_rows(shim, 3, 4, p, X, u, fast=True, force_general_pow=general_pow)
+        Ke6, Fe6 = shim_rows(shim, 6, 4, p, X, u, fast=True, force_general_pow=general_pow)
+        sK, sF = np.nanmax(np.abs(Ke0)), max(np.nanmax(np.abs(Fe0)), 1e-300)   # NaN (0/0 in Ve) must appear in the same places
+        np.testing.assert_allclose(Ke6, Ke0, rtol=1e-10, atol=1e-12 * sK)
+        np.testing.assert_allclose(Fe6, Fe0, rtol=1e-10, atol=1e-12 * sF)
+        np.testing.assert_allclose(Ke6, Ke3, rtol=1e-12, atol=1e-14 * sK)
+        np.testing.assert_allclose(Fe6, Fe3, rtol=1e-12, atol=1e-14 * sF)
+    X, u, aux, pf = _case(0, 4, 1, "full")      # any cell transport term on: refused, like the coefficient-form variant
+    acc, fe = np.empty((5, 5, 4)), np.empty(5)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert shim.shim_row(6, 4, 1, 0, C.byref(pf), dp(np.ascontiguousarray(X)), dp(np.ascontiguousarray(u)), None, 0, dp(acc), dp(fe), None) == 3
