@@ -28,6 +28,17 @@ elif a.model == "ripf":
     p, nv = ripf_params_from_dict(synth.ripf_param_dict(a.params)), 3
     u, aux = synth.ripf_fields(xyz)
     run = ctx.assemble_ripf
+elif a.model == "adpm":
+    from rdcfes_amd import adpm_params_from_dict
+    from rdcfes_amd.context import FIELD_ELEM_FIBRE
+    p, nv, aux = adpm_params_from_dict(synth.adpm_param_dict("full"), time=3.0), 3, None
+    u, tracts = synth.adpm_fields(xyz, conn.shape[0])
+    run = ctx.assemble_adpm
+elif a.model == "proteas":
+    from rdcfes_amd import proteas_params_from_dict
+    p, nv = proteas_params_from_dict(synth.proteas_param_dict("full")), 5
+    u, aux = synth.proteas_fields(xyz)
+    run = ctx.assemble_proteas
 else:
     p, u, aux, nv = hcc_params_from_dict(synth.hcc_param_dict(a.params)), synth.hcc_fields(xyz), None, 3
     run = ctx.assemble_hcc
@@ -35,6 +46,8 @@ ctx.mesh_upload(4, conn, xyz, nv)
 ctx.field_upload(FIELD_OLD_SOLUTION, u)
 if aux is not None:
     ctx.field_upload(FIELD_AUX_NODAL, aux)
+if a.model == "adpm":
+    ctx.field_upload(FIELD_ELEM_FIBRE, tracts)
 ctx.set_scatter(a.scatter)
 ctx.timing_enable(True)
 res = {s: [] for s in a.sets}
