@@ -119,5 +119,36 @@ RDC_HD void fe_point(const double (&X)[NEN][3], int q, double (&N)[NEN], double 
   JxW = det * w;
 }
 
+// HEX8: inverse Jacobian and JxW only.  The generic row evaluator needs the physical gradient of ONE node (the row
+// node) and of the interpolated fields, so it applies Ji to those few reference gradients instead of forming
+// grad phi of all eight nodes (72 multiply-adds per point, rdc_row.h).
+RDC_HD void fe_jacobian8(const double (&X)[8][3], int q, double (&Ji)[3][3], double& JxW) {
+  double J[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+#pragma unroll
+      for (int n = 0; n < 8; n++) s += X[n][r] * kHex8Tab.dN[q][n][c];
+      J[r][c] = s;
+    }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  const double s = rcp(det);  // v_rcp_f64 + 2 Newton steps: <= 1 ulp
+  Ji[0][0] = c00 * s;
+  Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * s;
+  Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * s;
+  Ji[1][0] = c01 * s;
+  Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * s;
+  Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * s;
+  Ji[2][0] = c02 * s;
+  Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * s;
+  Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * s;
+  JxW = det;  // Gauss weight 1
+}
+
 }  // namespace rdc
 #endif
