@@ -187,7 +187,11 @@ int rdc_set_scatter(rdc_ctx* ctx, int strategy);
 int rdc_get_scatter(const rdc_ctx* ctx, int* strategy);
 int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
 /* tuning / profiling knobs, not needed for normal use.  "occupancy": launch-bound waves per SIMD of
- * the TET4 row-gather kernel; "ablate": 1/2 remove parts of that kernel (results are then WRONG).
+ * the TET4 row-gather kernel; "ablate": 1..6 remove parts of that kernel (results are then WRONG);
+ * "moments": 1 (default) evaluates PIHNA/TET4 rows in moment form when the parameters have the shipped pattern (cell
+ * transport off), 0 in coefficient form -- same sums, other association; "specialise": 0 disables that parameter-
+ * pattern variant altogether; "kernel", "staged", "slim", "stagger", "prefetch", "xcd", "schedule", "block", "grid",
+ * "solid_kernel", "solid_gather", "solid_split", "solid_store" select alternative / diagnostic kernels.
  * Two-part assembly, for overlapping a halo exchange with the assembly of rows that do not need it:
  * "interior_nodes" = n states that no element of the owned nodes [0, n) contains a ghost node (the caller numbers
  * its owned nodes interior-first); with "part" = 1 an assemble call then writes only the rows of leading workgroups
