@@ -396,3 +396,31 @@ def test_two_part_assembly_equals_whole(frac):
     first_untouched = 5 * n_int
     assert np.array_equal(vala[rp[first_untouched]:], val1[rp[first_untouched]:])
     assert rel(valb, val0) < 1e-13 and rel(rhsb, rhs0) < 1e-13
+
+
+def test_two_part_assembly_fallback_paths():
+    """Paths that cannot launch sub-ranges (HEX8 generic kernels, the coloured strategy) write nothing in part 1 and
+    everything in part 2 -- the contract rdc_assembly.h states for rdc_set_option("part")."""
+    conn, xyz = synth.hex_mesh(6, jitter=0.1, order="random")
+    u = synth.hcc_fields(xyz)
+    p = hcc_params_from_dict(synth.hcc_param_dict("full"))
+    for nen, strategy in [(8, SCATTER_ROWGATHER), (8, SCATTER_COLOURED)]:
+        with AssemblyContext(0) as ctx:
+            ctx.set_scatter(strategy)
+            ctx.mesh_upload(nen, conn, xyz, 3)
+            ctx.field_upload(FIELD_OLD_SOLUTION, u)
+            ctx.assemble_hcc(p)
+            val0, rhs0 = ctx.csr_download()
+            ctx.field_upload(FIELD_OLD_SOLUTION, 0.5 * u)
+            ctx.assemble_hcc(p)
+            val1, rhs1 = ctx.csr_download()
+            ctx.field_upload(FIELD_OLD_SOLUTION, u)
+            ctx.set_option("interior_nodes", xyz.shape[0] // 2)
+            ctx.set_option("part", 1)
+            ctx.assemble_hcc(p)
+            vala, rhsa = ctx.csr_download()
+            assert np.array_equal(vala, val1) and np.array_equal(rhsa, rhs1)     # untouched
+            ctx.set_option("part", 2)
+            ctx.assemble_hcc(p)
+            valb, rhsb = ctx.csr_download()
+            assert rel(valb, val0) < 1e-13 and rel(rhsb, rhs0) < 1e-13
