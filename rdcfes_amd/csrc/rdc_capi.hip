@@ -40,6 +40,7 @@ struct rdc_ctx {
   int opt_part = 0;            // 0 = whole mesh, 1 = workgroups of interior nodes only, 2 = the remaining workgroups
   int64_t opt_interior = -1;   // owned nodes [0, opt_interior) have no ghost node in any of their elements
   int opt_stagger = 0;
+  int opt_ldspad = 0;
   int opt_moments = 1;  // PIHNA (cell transport off) TET4: moment form of the rows
   int opt_slim = 0;     // PIHNA: slim per-point state (re-derived per equation row); with occupancy=3 three waves per SIMD
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
@@ -243,6 +244,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_slim = c->opt_slim;
   a.opt_moments = c->opt_moments;
   a.opt_stagger = c->opt_stagger;
+  a.opt_ldspad = c->opt_ldspad;
   a.opt_xcd = c->opt_xcd;
   a.opt_grid = c->opt_grid;
   a.opt_pf = c->opt_pf;
@@ -401,6 +403,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   }
   else if (!std::strcmp(key, "specialise")) c->opt_special = value;
   else if (!std::strcmp(key, "slim")) c->opt_slim = value;
+  else if (!std::strcmp(key, "lds_pad")) c->opt_ldspad = value;  // k_tet4_rg5: KB of unused LDS per workgroup (diagnostic: fewer co-resident workgroups)
   else if (!std::strcmp(key, "stagger")) c->opt_stagger = value;  // k_tet4_rg5: start delay of every CU's second workgroup, in units of 1024 cycles
   else if (!std::strcmp(key, "moments")) c->opt_moments = value;  // 1 (default): shipped-pattern PIHNA/TET4 rows in moment form (rdc_tet4_pihna_moments.h), 0: coefficient form
   else if (!std::strcmp(key, "interior_nodes")) c->opt_interior = value;  // see rdc_assembly.h (two-part assembly)

@@ -48,7 +48,7 @@ struct LaunchArgs {
   const double* elem = nullptr;  // per-element inputs ([n_elem][M::NELEM]) of models that have them (ADPM tracts)
   double* packed;  // scratch for the per-node records of the TET4 fast path
   int variant;     // RDC_VARIANT_*
-  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf, opt_slim = 0, opt_moments = 1, opt_stagger = 0;  // tuning knobs (rdc_set_option)
+  int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf, opt_slim = 0, opt_moments = 1, opt_stagger = 0, opt_ldspad = 0;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;

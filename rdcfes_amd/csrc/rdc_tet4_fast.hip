@@ -790,7 +790,8 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
     constexpr int BLOCK = 256;
     const int nl = a.rg2.nl_stride;
     const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 3) & ~(size_t)1);  // + slice phase shift + diagonal alignment
-    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + (size_t)(Rec<M>::N / 2) * nl * 2);
+    // + opt_ldspad KB of unused LDS: diagnostic, lowers the number of co-resident workgroups (one per CU from ~55 KB)
+    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + (size_t)(Rec<M>::N / 2) * nl * 2) + (size_t)a.opt_ldspad * 1024;
     const int wg_begin = a.rg2.wg_begin, wg_count = a.rg2.wg_count < 0 ? a.rg2.n_wg - a.rg2.wg_begin : a.rg2.wg_count;
     if (wg_count <= 0) return hipSuccess;
 #define RDC_RG5(MINW, ST)                                                                                          \
