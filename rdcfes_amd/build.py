@@ -38,6 +38,8 @@ CXXFLAGS = [
     "-fopenmp", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed",
     "-ffp-contract=fast",
 ]
+# experiments only: extra compiler flags for every HIP source, e.g. RDC_EXTRA_HIPCC_FLAGS="-mllvm -amdgpu-enable-max-ilp-scheduling-strategy=1"
+CXXFLAGS += os.environ.get("RDC_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def hipcc() -> str:
