@@ -424,3 +424,32 @@ def test_two_part_assembly_fallback_paths():
             ctx.assemble_hcc(p)
             valb, rhsb = ctx.csr_download()
             assert rel(valb, val0) < 1e-13 and rel(rhsb, rhs0) < 1e-13
+
+
+@pytest.mark.parametrize("moments", [1, 0])
+def test_pihna_shipped_pattern_branches(oracle, moments):
+    """The shipped-pattern PIHNA kernels (moment form and coefficient form) on a state that exercises the clamped
+    branches on the GPU too: saturated and empty crowding, vascular fraction at 0 and 1, vasculature below the diffusion
+    threshold, and a patch of all-zero nodes (0/0 in the vascular fraction -> NaN in the same entries as the oracle)."""
+    conn, xyz = synth.kuhn_tet_mesh(8, order="random")
+    rng = np.random.default_rng(5)
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    x = xyz[:, 0]
+    u[x < 0.25, :4] *= 60.0                                   # Te >= 1
+    u[(x >= 0.25) & (x < 0.4), 3] = rng.uniform(0.0, 2.0 * p.cells_min_capacity, int(((x >= 0.25) & (x < 0.4)).sum()))
+    u[(x >= 0.4) & (x < 0.5), 1:3] = 0.0                      # Ve = 1
+    u[(x >= 0.5) & (x < 0.6), 3] = 0.0                        # Ve = 0
+    u[x > 0.7] = 0.0                                          # empty
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("moments", moments)
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val, rhs = ctx.csr_download()
+    assert np.array_equal(np.isnan(val), np.isnan(val0)) and np.array_equal(np.isnan(rhs), np.isnan(rhs0))
+    assert np.isnan(val0).any()
+    ok, okr = ~np.isnan(val0), ~np.isnan(rhs0)
+    assert rel(val[ok], val0[ok]) < TOL and rel(rhs[okr], rhs0[okr]) < TOL
+    np.testing.assert_allclose(val[ok], val0[ok], rtol=1e-9, atol=1e-12 * np.abs(val0[ok]).max())
