@@ -205,6 +205,12 @@ hipError_t launch_specialised<Pihna, rdc_pihna_params>(const LaunchArgs& a, cons
   return launch_rd<Pihna>(a, k);
 }
 
+template <>
+hipError_t launch_specialised<Ripf, rdc_ripf_params>(const LaunchArgs& a, const Ripf::K& k, const rdc_ripf_params& p) {
+  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && RipfReduced::applies(p)) return launch_tet4_fast<RipfReduced>(a, k);
+  return launch_rd<Ripf>(a, k);
+}
+
 template <class M, class P>
 int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (!c) return RDC_ERR_INVALID;

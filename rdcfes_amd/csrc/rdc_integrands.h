@@ -457,6 +457,82 @@ struct Ripf {
   }
 };
 
+// RIPF with the cancer-growth, HU-rate, second fibrosis source and radiotaxis terms switched off: kappa = omicro =
+// radiotaxis = 0 and every HU/phi rate = 0 exactly -- the shipped run/RIPF133/input.dat, where only the radiotherapy
+// kill of cc and the HU-driven fibrosis with diffusion + haptotaxis act.  Upstream multiplies by those zeros
+// (0 * finite = 0), so dropping the products is exact for finite states: one exp instead of two per point, no unit
+// radiotherapy gradient, 5 instead of 8 coefficient blocks, and a 7-double point state (Ripf: 10).  The host selects
+// this variant from the parameter values; anything else uses Ripf.
+struct RipfReduced : Ripf {
+  static inline bool applies(const rdc_ripf_params& p) {
+    return p.kappa == 0.0 && p.kappa_RT_c >= 0.0 && p.omicro == 0.0 && p.radiotaxis == 0.0 && p.phi_cc_B == 0.0 &&
+           p.phi_cc_D == 0.0 && p.phi_cc == 0.0 && p.phi_fb_B == 0.0 && p.phi_fb_D == 0.0 && p.phi_fb == 0.0;
+  }
+  RDC_HD static constexpr bool hasA(int a, int b) { return (a == 0 && b == 0) || (a == 1 && b == 1) || a == 2; }
+  RDC_HD static constexpr bool hasB(int a, int b, int k) { return a == 2 && b >= 1 && k < 2; }
+  RDC_HD static constexpr bool hasD(int a, int b) { return a == 2 && (b == 0 || b == 2); }
+  RDC_HD static constexpr bool hasRG(int a, int k) { return a == 2 && k < 2; }
+
+  struct Pt { double HU, cc, fb, RT, delta_RT, Tau, dTau; };
+
+  template <int EXP_MODE>
+  RDC_HD static void point(const K& k, const double* u, const double* aux, Pt& s) {
+    s.HU = u[0]; s.cc = u[1]; s.fb = u[2];
+    const double RT = aux[2];
+    s.RT = RT;
+    s.delta_RT = k.delta * (1.0 - exp(-k.delta_RT_a * RT - k.delta_RT_b * (RT * RT)));  // :487
+    const double VF = k.VF_fixed + (s.cc + s.fb);                                     // :498-499
+    s.Tau = 0.0; s.dTau = 0.0;
+    if (VF < 1.0) {                                                                   // :503-514
+      double p, pm1;
+      pow_pair<EXP_MODE>(1.0 - VF, k.VF_exp, p, pm1);
+      s.Tau = p;
+      s.dTau = -k.VF_exp * pm1;
+      if (s.Tau < k.VF_min) { s.Tau = 0.0; s.dTau = 0.0; }
+    }
+  }
+
+  RDC_HD static void coef(const K& k, const Pt& p, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    const double lambda_RT = k.lambda * (p.RT * k.i_lambda_RT_r);                      // :488
+    double Lom = 0.0, Lom_dHU = 0.0, Lom_dfb = 0.0;                                    // :525-547
+    if (p.fb >= 0.0 && p.fb < 1.0) {
+      const double f2 = 1.0 - p.fb * p.fb;
+      if (p.HU > k.lambda_HU_r && p.HU < 0.0) {
+        Lom = f2 * (p.HU * k.i_lambda_HU_r);
+        Lom_dHU = f2 * k.i_lambda_HU_r;
+        Lom_dfb = -(2.0 * p.fb) * (p.HU * k.i_lambda_HU_r);
+      } else if (p.HU < k.lambda_HU_r) {
+        Lom = f2;
+        Lom_dfb = -(2.0 * p.fb);
+      }
+    }
+    // HU equation: every rate is zero
+    o.R[0] = p.HU;
+    o.A[0][0] = 1.0;
+    // cc equation: radiotherapy kill only
+    o.R[1] = p.cc - T * (p.delta_RT * p.cc);
+    o.A[1][1] = 1.0 + T * p.delta_RT;
+    // fb equation, :584-594, :629-662 without the omicro and radiotaxis terms
+    const double src = lambda_RT * p.dTau * Lom;
+    o.R[2] = p.fb + T * (lambda_RT * p.Tau * Lom - k.omega * p.fb);
+    o.RG[2][0] = -T * k.diffusion * p.Tau;
+    o.RG[2][1] = -T * k.haptotaxis * p.Tau * p.fb;
+    o.A[2][0] = -T * (lambda_RT * p.Tau * Lom_dHU);
+    o.D[2][0] = T * k.haptotaxis * p.Tau * p.fb;
+    o.A[2][1] = -T * src;
+    o.A[2][2] = 1.0 - T * (src + lambda_RT * p.Tau * Lom_dfb - k.omega);
+    {
+      const double b0 = T * k.diffusion * p.dTau, b1 = T * k.haptotaxis * p.dTau * p.fb;
+      o.B[2][1][0] = b0; o.B[2][1][1] = b1;
+      o.B[2][2][0] = b0;
+      o.B[2][2][1] = b1 + T * k.haptotaxis * p.Tau;
+    }
+    o.D[2][2] = T * k.diffusion * p.Tau;
+  }
+};
+
 // =========================================================================================
 // HCC: unknowns (l, c, n); gradient field 0 = c.  GRAD_sigma == 0 (src/coupled_hcc.C:508), so
 // every mechano term vanishes and is omitted.  Quirks kept: spurious capacity term in blocks

@@ -910,6 +910,7 @@ template hipError_t launch_tet4_fast<PihnaNoCellTransport>(const LaunchArgs&, co
 template hipError_t launch_tet4_fast<PihnaNoCellTransportSlim>(const LaunchArgs&, const PihnaNoCellTransportSlim::K&);
 template hipError_t launch_tet4_fast<PihnaNoCellTransportMoments>(const LaunchArgs&, const PihnaNoCellTransportMoments::K&);
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
+template hipError_t launch_tet4_fast<RipfReduced>(const LaunchArgs&, const RipfReduced::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
 template hipError_t launch_tet4_fast<Adpm>(const LaunchArgs&, const Adpm::K&);
 template hipError_t launch_tet4_fast<Proteas>(const LaunchArgs&, const Proteas::K&);

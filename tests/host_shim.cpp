@@ -124,6 +124,9 @@ int shim_row(int model, int nen, int fast, int force_general_pow, const void* pa
     case 3:  // PIHNA, cell-transport-off variant: only legal when the parameters allow it
       if (!PihnaNoCellTransport::applies(*(const rdc_pihna_params*)params)) return 3;
       return run<PihnaNoCellTransport>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 7:  // RIPF, reduced variant (growth / HU rates / second source / radiotaxis off): only legal for such parameters
+      if (!RipfReduced::applies(*(const rdc_ripf_params*)params)) return 3;
+      return run<RipfReduced>((const rdc_ripf_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
     case 6:  // the same in moment form (rdc_tet4_pihna_moments.h); TET4 factored row only
       if (!PihnaNoCellTransport::applies(*(const rdc_pihna_params*)params)) return 3;
       if (!fast || nen != 4) return 1;
@@ -139,6 +142,7 @@ int shim_masks(int model, const void* params, const double* u, const double* aux
     case 1: return masks<Ripf>((const rdc_ripf_params*)params, u, aux, worst);
     case 2: return masks<Hcc>((const rdc_hcc_params*)params, u, aux, worst);
     case 3: return masks<PihnaNoCellTransport>((const rdc_pihna_params*)params, u, aux, worst);
+    case 7: return masks<RipfReduced>((const rdc_ripf_params*)params, u, aux, worst);
     case 4: return masks<Adpm>((const rdc_adpm_params*)params, u, aux, worst);
     case 5: return masks<Proteas>((const rdc_proteas_params*)params, u, aux, worst);
   }

@@ -175,3 +175,38 @@ def test_pihna_moment_form_equals_coefficient_form(oracle, shim, general_pow):
     acc, fe = np.empty((5, 5, 4)), np.empty(5)
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     assert shim.shim_row(6, 4, 1, 0, C.byref(pf), dp(np.ascontiguousarray(X)), dp(np.ascontiguousarray(u)), None, 0, dp(acc), dp(fe), None) == 3
+
+
+@pytest.mark.parametrize("general_pow", [False, True])
+def test_ripf_reduced_variant(oracle, shim, general_pow):
+    """RipfReduced (kappa = omicro = radiotaxis = 0 and zero HU/phi rates: the shipped run/RIPF133/input.dat) against the
+    oracle's full upstream formulas and against the general Ripf rows, over states in every branch of the
+    fibrosis source (HU above / inside / below the ramp, fb outside [0,1), saturated volume fraction), and refused
+    when any of the dropped terms is switched on."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for seed in range(12):
+        X, u, aux, p = _case(1, 4, 500 + seed, "shipped")
+        if seed % 4 == 1:
+            u[:, 0] = rng.uniform(-1500.0, -900.0, 4)       # HU below the ramp
+        if seed % 4 == 2:
+            u[:, 0] = rng.uniform(10.0, 300.0, 4)           # HU >= 0: no source
+            u[:, 2] = rng.uniform(0.9, 1.2, 4)              # fb around 1
+        if seed % 4 == 3:
+            u[:, 1] = rng.uniform(0.3, 0.6, 4)              # volume fraction saturates at some points
+        Ke0, Fe0 = oracle.element(1, 4, X, u, p, aux=aux)
+        Ke1, Fe1 = shim_rows(shim, 1, 4, p, X, u, A=aux, fast=True, force_general_pow=general_pow)
+        Ke7, Fe7 = shim_rows(shim, 7, 4, p, X, u, A=aux, fast=True, force_general_pow=general_pow)
+        sK, sF = np.abs(Ke0).max(), max(np.abs(Fe0).max(), 1e-300)
+        np.testing.assert_allclose(Ke7, Ke0, rtol=1e-10, atol=1e-12 * sK)
+        np.testing.assert_allclose(Fe7, Fe0, rtol=1e-10, atol=1e-12 * sF)
+        np.testing.assert_allclose(Ke7, Ke1, rtol=1e-13, atol=1e-15 * sK)
+        np.testing.assert_allclose(Fe7, Fe1, rtol=1e-13, atol=1e-15 * sF)
+    w = C.c_double(-1.0)
+    un, an = np.ascontiguousarray(u[0]), np.ascontiguousarray(aux[0])
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert shim.shim_masks(7, C.byref(p), dp(un), dp(an), C.byref(w)) == 0 and w.value == 0.0
+    X, u, aux, pf = _case(1, 4, 1, "full")
+    acc, fe = np.empty((3, 3, 4)), np.empty(3)
+    assert shim.shim_row(7, 4, 1, 0, C.byref(pf), dp(np.ascontiguousarray(X)), dp(np.ascontiguousarray(u)),
+                         dp(np.ascontiguousarray(aux)), 0, dp(acc), dp(fe), None) == 3
