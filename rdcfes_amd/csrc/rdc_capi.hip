@@ -211,6 +211,18 @@ hipError_t launch_specialised<Ripf, rdc_ripf_params>(const LaunchArgs& a, const 
   return launch_rd<Ripf>(a, k);
 }
 
+// the all-rates-zero HCC of run/Coupled/HCC and the decay-only ADPM of run/HCP102513: any element type and kernel
+template <>
+hipError_t launch_specialised<Hcc, rdc_hcc_params>(const LaunchArgs& a, const Hcc::K& k, const rdc_hcc_params& p) {
+  if (a.variant != RDC_VARIANT_GENERIC && a.opt_special && HccMassOnly::applies(p)) return launch_rd<HccMassOnly>(a, k);
+  return launch_rd<Hcc>(a, k);
+}
+template <>
+hipError_t launch_specialised<Adpm, rdc_adpm_params>(const LaunchArgs& a, const Adpm::K& k, const rdc_adpm_params& p) {
+  if (a.variant != RDC_VARIANT_GENERIC && a.opt_special && AdpmDecayOnly::applies(p)) return launch_rd<AdpmDecayOnly>(a, k);
+  return launch_rd<Adpm>(a, k);
+}
+
 template <class M, class P>
 int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (!c) return RDC_ERR_INVALID;

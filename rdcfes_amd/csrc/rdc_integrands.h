@@ -612,6 +612,31 @@ struct Hcc {
   }
 };
 
+// HCC with every rate zero (produce/l, produce/c, diffuse/c, necrosis/l, necrosis/c = 0 exactly): the shipped
+// run/Coupled/HCC/input.dat, which gives only the capacity keys.  What is left of src/coupled_hcc.C:540-637 are the
+// mass-type blocks with upstream's constants -- including the spurious capacity blocks [0][1], [0][2], [1][0] = 1 and
+// the doubled [1][1] = 2 (App. D.1-2) -- and rhs = old solution; the blocks [2][0], [2][1] are -T*0*n = -0.  No
+// gradient, no pow.  Exact for finite states; the host selects it from the parameter values.
+struct HccMassOnly : Hcc {
+  static inline bool applies(const rdc_hcc_params& p) {
+    return p.produce_l == 0.0 && p.produce_c == 0.0 && p.diffuse_c == 0.0 && p.necrosis_l == 0.0 && p.necrosis_c == 0.0;
+  }
+  RDC_HD static constexpr bool hasA(int a, int b) { return a == 0 || (a == 1 && b <= 1) || (a == 2 && b == 2); }
+  RDC_HD static constexpr bool hasB(int, int, int) { return false; }
+  RDC_HD static constexpr bool hasD(int, int) { return false; }
+  RDC_HD static constexpr bool hasRG(int, int) { return false; }
+  struct Pt { double l, c, n; };
+  template <int EXP_MODE>
+  RDC_HD static void point(const K&, const double* u, const double* /*aux*/, Pt& s) { s.l = u[0]; s.c = u[1]; s.n = u[2]; }
+  RDC_HD static void coef(const K&, const Pt& s, C& o) {
+    o.zero();
+    o.R[0] = s.l; o.R[1] = s.c; o.R[2] = s.n;
+    o.A[0][0] = 1.0; o.A[0][1] = 1.0; o.A[0][2] = 1.0;
+    o.A[1][0] = 1.0; o.A[1][1] = 2.0;
+    o.A[2][2] = 1.0;
+  }
+};
+
 // exponent -> EXP_MODE (0 = general pow)
 // =========================================================================================
 // ADPM (src/adpm.C:324-652): unknowns (PrP, A_b, Tau).  Gradient fields: 0 = grad A_b, 1 = grad Tau,
@@ -775,6 +800,35 @@ struct Adpm {
     o.D[2][2] = T * s.difT;
     o.B[2][2][3] = T * s.t1T;
     o.B[2][2][2] = -T * s.t2T;
+  }
+};
+
+// ADPM with only the decay terms on: transform, production, A_b decay, diffusion and both taxis magnitudes <= 0 (every
+// such piecewise rate returns 0, src/utils.h:100-187) -- the shipped run/HCP102513/input.dat as the code reads it.
+// Left: the PrP decay pulse and the Tau decay, i.e. three diagonal mass-type blocks; no gradient field, no tract
+// vector.  Exact for finite states; the host selects it from the parameter values.
+struct AdpmDecayOnly : Adpm {
+  static constexpr int NELEM = 0;  // the tract vectors are not read
+  RDC_HD static void grad_post(const AdpmK&, double (*)[3], const double*) {}
+  static inline bool applies(const rdc_adpm_params& p) {
+    return p.transform_A_b[0] <= 0.0 && p.transform_Tau[0] <= 0.0 && p.produce_A_b[0] <= 0.0 && p.produce_Tau[0] <= 0.0 &&
+           p.decay_A_b[0] <= 0.0 && p.diffuse_A_b[0] <= 0.0 && p.diffuse_Tau[0] <= 0.0 && p.taxis1_A_b[0] <= 0.0 &&
+           p.taxis2_A_b[0] <= 0.0 && p.taxis1_Tau[0] <= 0.0 && p.taxis2_Tau[0] <= 0.0;
+  }
+  RDC_HD static constexpr bool hasA(int a, int b) { return a == b; }
+  RDC_HD static constexpr bool hasB(int, int, int) { return false; }
+  RDC_HD static constexpr bool hasD(int, int) { return false; }
+  RDC_HD static constexpr bool hasRG(int, int) { return false; }
+  RDC_HD static void coef(const K& k, const Pt& p, C& o) {
+    o.zero();
+    const double T = k.DT2;
+    const double PiP = pw_Pi(p.PrP, k.decay_PrP), decT = pw_Pi(p.Tau, k.decay_Tau);
+    o.R[0] = p.PrP + T * (-PiP * p.PrP);          // :497-504 with TrA = TrT = 0
+    o.A[0][0] = 1.0 - T * (-PiP);
+    o.R[1] = p.A_b;                               // :506-518 with every rate 0
+    o.A[1][1] = 1.0;
+    o.R[2] = p.Tau + T * (-decT * p.Tau);         // :520-532
+    o.A[2][2] = 1.0 - T * (-decT);
   }
 };
 

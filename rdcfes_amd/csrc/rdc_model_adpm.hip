@@ -2,4 +2,5 @@
 #include "rdc_launch.h"
 namespace rdc {
 template hipError_t launch_rd<Adpm>(const LaunchArgs&, const Adpm::K&);
+template hipError_t launch_rd<AdpmDecayOnly>(const LaunchArgs&, const AdpmDecayOnly::K&);
 }

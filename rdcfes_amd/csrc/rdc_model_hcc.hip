@@ -2,4 +2,5 @@
 #include "rdc_launch.h"
 namespace rdc {
 template hipError_t launch_rd<Hcc>(const LaunchArgs&, const Hcc::K&);
+template hipError_t launch_rd<HccMassOnly>(const LaunchArgs&, const HccMassOnly::K&);
 }

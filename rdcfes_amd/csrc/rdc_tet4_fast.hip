@@ -912,7 +912,9 @@ template hipError_t launch_tet4_fast<PihnaNoCellTransportMoments>(const LaunchAr
 template hipError_t launch_tet4_fast<Ripf>(const LaunchArgs&, const Ripf::K&);
 template hipError_t launch_tet4_fast<RipfReduced>(const LaunchArgs&, const RipfReduced::K&);
 template hipError_t launch_tet4_fast<Hcc>(const LaunchArgs&, const Hcc::K&);
+template hipError_t launch_tet4_fast<HccMassOnly>(const LaunchArgs&, const HccMassOnly::K&);
 template hipError_t launch_tet4_fast<Adpm>(const LaunchArgs&, const Adpm::K&);
+template hipError_t launch_tet4_fast<AdpmDecayOnly>(const LaunchArgs&, const AdpmDecayOnly::K&);
 template hipError_t launch_tet4_fast<Proteas>(const LaunchArgs&, const Proteas::K&);
 
 }  // namespace rdc

@@ -112,7 +112,7 @@ def make_prep(shim):
 
 def shim_rows(lib, model, nen, params, X, U, A=None, fast=False, force_general_pow=False, elem_data=None):
     """all rows through the product's row function -> (Ke [nv*nen][nv*nen] var-major, Fe)"""
-    nv = {0: 5, 1: 3, 2: 3, 3: 5, 4: 3, 5: 5, 6: 5, 7: 3}[model]
+    nv = {0: 5, 1: 3, 2: 3, 3: 5, 4: 3, 5: 5, 6: 5, 7: 3, 8: 3, 9: 3}[model]
     ED = None if elem_data is None else np.ascontiguousarray(elem_data, dtype=np.float64)
     X = np.ascontiguousarray(X, dtype=np.float64)
     U = np.ascontiguousarray(U, dtype=np.float64)

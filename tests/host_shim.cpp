@@ -124,6 +124,12 @@ int shim_row(int model, int nen, int fast, int force_general_pow, const void* pa
     case 3:  // PIHNA, cell-transport-off variant: only legal when the parameters allow it
       if (!PihnaNoCellTransport::applies(*(const rdc_pihna_params*)params)) return 3;
       return run<PihnaNoCellTransport>((const rdc_pihna_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 8:  // HCC with every rate zero (run/Coupled/HCC)
+      if (!HccMassOnly::applies(*(const rdc_hcc_params*)params)) return 3;
+      return run<HccMassOnly>((const rdc_hcc_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);
+    case 9:  // ADPM, decay terms only (run/HCP102513)
+      if (!AdpmDecayOnly::applies(*(const rdc_adpm_params*)params)) return 3;
+      return run<AdpmDecayOnly>((const rdc_adpm_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe, ED);
     case 7:  // RIPF, reduced variant (growth / HU rates / second source / radiotaxis off): only legal for such parameters
       if (!RipfReduced::applies(*(const rdc_ripf_params*)params)) return 3;
       return run<RipfReduced>((const rdc_ripf_params*)params, nen, fast, force_general_pow, X, U, A, irow, acc, fe);

@@ -55,7 +55,7 @@ def _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, n_owned=N
 
 
 COMBOS = [(m, nen, s, v, pv)
-          for m, pvs in ((0, ("full", "shipped", "realexp")), (1, ("full", "shipped")), (2, ("full",)))
+          for m, pvs in ((0, ("full", "shipped", "realexp")), (1, ("full", "shipped")), (2, ("full", "shipped")))
           for pv in pvs
           for nen in (4, 8)
           for s in (SCATTER_COLOURED, SCATTER_ROWGATHER)

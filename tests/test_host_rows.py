@@ -210,3 +210,37 @@ def test_ripf_reduced_variant(oracle, shim, general_pow):
     acc, fe = np.empty((3, 3, 4)), np.empty(3)
     assert shim.shim_row(7, 4, 1, 0, C.byref(pf), dp(np.ascontiguousarray(X)), dp(np.ascontiguousarray(u)),
                          dp(np.ascontiguousarray(aux)), 0, dp(acc), dp(fe), None) == 3
+
+
+@pytest.mark.parametrize("nen", [4, 8])
+def test_shipped_pattern_variants_of_hcc_and_adpm(oracle, shim, nen):
+    """HccMassOnly (run/Coupled/HCC: every rate zero) and AdpmDecayOnly (run/HCP102513: decay terms only) against the
+    oracle's full formulas and against the general rows; refused for parameters with any dropped term on."""
+    import ctypes as C
+    from rdcfes_amd import adpm_params_from_dict
+    dp = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.POINTER(C.c_double))
+    for seed in range(6):
+        X, u, aux, p = _case(2, nen, 700 + seed, "shipped")
+        Ke0, Fe0 = oracle.element(2, nen, X, u, p)
+        for fast in ((False, True) if nen == 4 else (False,)):
+            Ke8, Fe8 = shim_rows(shim, 8, nen, p, X, u, fast=fast)
+            Ke2, Fe2 = shim_rows(shim, 2, nen, p, X, u, fast=fast)
+            np.testing.assert_allclose(Ke8, Ke0, rtol=1e-10, atol=1e-13 * np.abs(Ke0).max())
+            np.testing.assert_allclose(Fe8, Fe0, rtol=1e-10, atol=1e-13 * np.abs(Fe0).max())
+            np.testing.assert_allclose(Ke8, Ke2, rtol=1e-13, atol=1e-15 * np.abs(Ke0).max())
+        rng = np.random.default_rng(800 + seed)
+        pa = adpm_params_from_dict(synth.adpm_param_dict("shipped"), time=2.0)
+        ua = np.column_stack([rng.uniform(0.0, 12.0, nen), rng.uniform(0.0, 0.02, nen), rng.uniform(0.0, 0.001, nen)])
+        t = 0.1 * rng.standard_normal(3)
+        Ka0, Fa0 = oracle.element(oracle.MODEL_ADPM, nen, X, ua, pa, elem_data=t)
+        for fast in ((False, True) if nen == 4 else (False,)):
+            Ka9, Fa9 = shim_rows(shim, 9, nen, pa, X, ua, elem_data=t, fast=fast)
+            Ka4, Fa4 = shim_rows(shim, 4, nen, pa, X, ua, elem_data=t, fast=fast)
+            np.testing.assert_allclose(Ka9, Ka0, rtol=1e-10, atol=1e-13 * np.abs(Ka0).max())
+            np.testing.assert_allclose(Fa9, Fa0, rtol=1e-10, atol=1e-13 * np.abs(Fa0).max())
+            np.testing.assert_allclose(Ka9, Ka4, rtol=1e-13, atol=1e-15 * np.abs(Ka0).max())
+    X, u, aux, pf = _case(2, nen, 1, "full")
+    acc, fe = np.empty((3, 3, nen)), np.empty(3)
+    assert shim.shim_row(8, nen, 0, 0, C.byref(pf), dp(X), dp(u), None, 0, dp(acc), dp(fe), None) == 3
+    paf = adpm_params_from_dict(synth.adpm_param_dict("full"), time=2.0)
+    assert shim.shim_row(9, nen, 0, 0, C.byref(paf), dp(X), dp(u), None, 0, dp(acc), dp(fe), dp(np.zeros(3))) == 3

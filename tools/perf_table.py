@@ -35,7 +35,7 @@ def run(name, nen, conn, xyz, nv, setup, call, scatter, reps=10, n_in=None, soli
                           "B_alg_per_elem": round(B / conn.shape[0], 1), "GBps_alg": round(B / ms / 1e6, 1), "frac_of_8TBps": round(B / ms / 1e6 / 8000, 4),
                           "colours": ctx.n_colours(), "prep_s": round(prep, 2)}), flush=True)
 
-which = sys.argv[1:] or ["pihna55", "pihna119", "ripf94", "hcc_tet", "adpm94", "proteas94", "hcc126", "adpm100hex", "solid63", "solid126", "solid60tet", "pihna119_random"]
+which = sys.argv[1:] or ["pihna55", "pihna119", "ripf94", "hcc_tet", "adpm94", "proteas94", "hcc126", "hcc126_shipped", "adpm100hex", "adpm94_shipped", "solid63", "solid126", "solid60tet", "pihna119_random"]
 for w in which:
     if w.startswith("pihna"):
         order = "random" if w.endswith("random") else "lex"
@@ -65,14 +65,19 @@ for w in which:
             c.field_upload(FIELD_OLD_SOLUTION, u); c.field_upload(FIELD_AUX_NODAL, aux)
         run(f"PROTEAS {'HEX8 H' if hexm else 'TET4 K'}({n})", 8 if hexm else 4, conn, xyz, 5, setup, lambda c: c.assemble_proteas(p), 2, reps=6, n_in=6)
     elif w.startswith("adpm"):
-        hexm = w.endswith("hex")
-        n = int(w.replace("adpm", "").replace("hex", "") or 60)
+        hexm = w.replace("_shipped", "").endswith("hex")
+        n = int(w.replace("adpm", "").replace("_shipped", "").replace("hex", "") or 60)
         conn, xyz = synth.hex_mesh(n, jitter=0.1) if hexm else synth.kuhn_tet_mesh(n)
         u, tracts = synth.adpm_fields(xyz, conn.shape[0])
-        p = adpm_params_from_dict(synth.adpm_param_dict("full"), time=3.0)
+        shipped = w.endswith("_shipped")
+        p = adpm_params_from_dict(synth.adpm_param_dict("shipped" if shipped else "full"), time=3.0)
         def setup(c):
             c.field_upload(FIELD_OLD_SOLUTION, u); c.field_upload(FIELD_ELEM_FIBRE, tracts)
-        run(f"ADPM {'HEX8 H' if hexm else 'TET4 K'}({n})", 8 if hexm else 4, conn, xyz, 3, setup, lambda c: c.assemble_adpm(p), 2, reps=6)
+        run(f"ADPM {'HEX8 H' if hexm else 'TET4 K'}({n})" + (", shipped run/HCP102513 parameters (decay only)" if shipped else ""), 8 if hexm else 4, conn, xyz, 3, setup, lambda c: c.assemble_adpm(p), 2, reps=6)
+    elif w == "hcc126_shipped":   # run/Coupled/HCC/input.dat: every rate zero -> HccMassOnly
+        conn, xyz = synth.hex_mesh(126, jitter=0.1)
+        p, u = hcc_params_from_dict(synth.hcc_param_dict("shipped")), synth.hcc_fields(xyz)
+        run("HCC HEX8 H(126), shipped run/Coupled/HCC parameters (all rates zero)", 8, conn, xyz, 3, lambda c: c.field_upload(FIELD_OLD_SOLUTION, u), lambda c: c.assemble_hcc(p), 2, reps=6)
     elif w == "hcc126":
         conn, xyz = synth.hex_mesh(126, jitter=0.1)
         p, u = hcc_params_from_dict(synth.hcc_param_dict("full")), synth.hcc_fields(xyz)
