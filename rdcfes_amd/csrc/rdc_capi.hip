@@ -441,7 +441,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     if (value != 0 && value != 1) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (two-pass) or 1 (coloured)");
     c->opt_solid_kernel = value;
   }
-  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = default (LDS-staged node records, k_tet4_rg5), 3 = k_tet4_rg3, 4 = persistent k_tet4_rg4,
+  else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = default (LDS-staged node records, k_tet4_rg5), 3 = k_tet4_rg3, 4 = persistent k_tet4_rg4, 6 = k_tet4_rg6 (rg5 over work items with a tail prefetch, experimental),
                                                                  // 1 = first row-gather kernel, 2 = staged deterministic k_tet4_rg2
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
   return RDC_OK;

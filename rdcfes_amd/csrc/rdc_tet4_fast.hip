@@ -432,6 +432,151 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   }
 }
 
+// ---- k_tet4_rg5 walking over work items with a TAIL PREFETCH (experimental, rdc_set_option("kernel", 6)) ---------
+// Vector-memory operations of a wave complete in issue order, and a new workgroup's list loads sit behind the store
+// burst of the workgroup that just finished on its CU.  Here a workgroup keeps its CU slot and, right after the compute
+// barrier of item w, issues the list loads of item w + gridDim.x (registers are free then; they land during the fold),
+// then the LDS-DMA of that item's node records (the record area is dead once the compute phase has gathered from it),
+// and only then the stores of item w.  Models without per-element inputs only.
+template <class M, int EXP_MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
+k_tet4_rg6(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict__ pair_loc,
+           const uint16_t* __restrict__ pair_aux, const uint32_t* __restrict__ nlist,
+           const uint16_t* __restrict__ node_tab, const typename M::K k, const double* __restrict__ rec,
+           double* __restrict__ val, double* __restrict__ rhs, const int nl_stride, const int acc_doubles,
+           const int w_begin, const int w_end) {
+  constexpr int NV = M::NV, NW = BLOCK / 64, NC = HostPrep::rg3_diag_copies(BLOCK), NDV = NV * NV + NV;
+  constexpr int ns = HostPrep::RG3_DIAG_SLOTS, MAXN = ns / NC, NP = Rec<M>::N / 2;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // [accumulators | node records: NP x nl_stride x 16 B]
+  __shared__ uint2 ntab[MAXN];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = lane * NW + wv;
+  const int rounds = nl_stride >> 6;
+  double* const recs = lds + acc_doubles;
+  int w = w_begin + (int)blockIdx.x;
+  if (w >= w_end) return;
+  // prologue: lists and records of the first item
+  uint32_t nid = 0;
+  if (wv < rounds) nid = nlist[(size_t)w * nl_stride + wv * 64 + lane];
+  uint32_t pl = pair_loc[(size_t)w * BLOCK + idx];
+  uint4 ax = reinterpret_cast<const uint4*>(pair_aux)[(size_t)w * BLOCK + idx];
+  // only four fields of the 64-byte descriptor are kept (SGPRs are short: the model constants take ~80 of them, and a
+  // spilled register means scratch traffic, which shares vmcnt with the DMA and the stores)
+  struct Item { int n0, nnodes, nb; int64_t vb0; };
+  Item d = {desc[w].n0, desc[w].nnodes, desc[w].nb, desc[w].vb0};
+  uint2 nt = make_uint2(0u, 0u);
+  if ((int)threadIdx.x < d.nnodes) nt = reinterpret_cast<const uint2*>(node_tab)[d.n0 + threadIdx.x];
+  if (wv < rounds) {
+    const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(recs + (p * nl_stride + wv * 64) * 2), 16, 0, 0);
+  }
+  for (;;) {
+    const int wn = w + (int)gridDim.x;
+    const bool more = wn < w_end;
+    Item d2 = d;
+    if (more) { d2.n0 = desc[wn].n0; d2.nnodes = desc[wn].nnodes; d2.nb = desc[wn].nb; d2.vb0 = desc[wn].vb0; }  // scalar loads, long before they are needed
+    {  // zero the accumulators: the previous item's store phase has read them (barrier at the loop end)
+      double2* z = reinterpret_cast<double2*>(lds);
+      for (int x = threadIdx.x; x < acc_doubles / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);
+    }
+    if ((int)threadIdx.x < d.nnodes) ntab[threadIdx.x] = nt;
+    const int nval = d.nb * NV * NV, sh = (int)(d.vb0 & 1), dbase = (nval + sh + 1) & ~1;
+    double* const sl = lds + sh;
+    // This item's records have landed.  vmcnt(0) also waits for the previous item's stores (issued after the DMA); a
+    // counted wait (all but the wave's store instructions) + raw barrier + LDS reads the compiler cannot see would let
+    // them drain under the compute phase -- tried at the end of round 1, not yet correct.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pl != 0xFFFFFFFFu) {
+      double X[4][3], U[4][NV], AX[4][M::NAUX > 0 ? M::NAUX : 1];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int li = (pl >> (8 * j)) & 0xFF;
+        double r[2 * NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          const double2 v2 = reinterpret_cast<const double2*>(recs)[p * nl_stride + li];
+          r[2 * p] = v2.x; r[2 * p + 1] = v2.y;
+        }
+        X[j][0] = r[0]; X[j][1] = r[1]; X[j][2] = r[2];
+#pragma unroll
+        for (int v = 0; v < NV; v++) U[j][v] = r[3 + v];
+        if (M::NAUX > 0) {
+#pragma unroll
+          for (int v = 0; v < M::NAUX; v++) AX[j][v] = r[3 + NV + v];
+        } else {
+          AX[j][0] = 0.0;
+        }
+      }
+      LdsSink3<M, 0> sink;
+      sink.row = sl + (ax.x & 0xFFFF);
+      sink.stride = (int)(ax.x >> 16);
+      sink.dacc = lds + dbase + (int)((ax.y & 0xFFFF) / NV) * NC + (int)(ax.y >> 16);
+      sink.off[0] = 0; sink.off[1] = (int)(ax.z >> 16);
+      sink.off[2] = (int)(ax.w & 0xFFFF); sink.off[3] = (int)(ax.w >> 16);
+      tet4_row0<M, EXP_MODE>(k, X, U, AX, sink, nullptr);
+    }
+    __syncthreads();
+    // ---- tail prefetch: lists of the next item, issued before this item's stores -------------------------------
+    uint32_t nid2 = 0, pl2 = 0xFFFFFFFFu;
+    uint4 ax2 = make_uint4(0u, 0u, 0u, 0u);
+    uint2 nt2 = make_uint2(0u, 0u);
+    if (more) {
+      if (wv < rounds) nid2 = nlist[(size_t)wn * nl_stride + wv * 64 + lane];
+      pl2 = pair_loc[(size_t)wn * BLOCK + idx];
+      ax2 = reinterpret_cast<const uint4*>(pair_aux)[(size_t)wn * BLOCK + idx];
+      if ((int)threadIdx.x < d2.nnodes) nt2 = reinterpret_cast<const uint2*>(node_tab)[d2.n0 + threadIdx.x];
+    }
+    // fold of this item (as k_tet4_rg5)
+    for (int x = threadIdx.x; x < d.nnodes * NDV; x += BLOCK) {
+      const int v = x / d.nnodes, n = x - v * d.nnodes;
+      const double2* src = reinterpret_cast<const double2*>(lds + dbase + v * ns + n * NC);  // NC is even
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < NC / 2; c++) { const double2 t = src[c]; sum += t.x; sum += t.y; }
+      if (v < NV * NV) {
+        const uint2 q = ntab[n];
+        const int a = v / NV, b = v - a * NV;
+        sl[(q.x & 0xFFFF) + a * (int)(q.x >> 16) + (q.y & 0xFFFF) + b] = sum;
+      } else {
+        rhs[(int64_t)(d.n0 + n) * NV + (v - NV * NV)] = sum;
+      }
+    }
+    __syncthreads();
+    if (more) {  // records of the next item into the (now dead) record area
+      // every prefetched list value is consumed HERE, while no LDS-DMA is in flight: with one in flight the compiler
+      // would wait vmcnt(0) -- stores included -- at their first use
+      asm volatile("" :: "v"(nid2), "v"(pl2), "v"(ax2.x), "v"(ax2.y), "v"(ax2.z), "v"(ax2.w), "v"(nt2.x), "v"(nt2.y));
+      if (wv < rounds) {
+        const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid2 * (NP * 16);
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+          __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(recs + (p * nl_stride + wv * 64) * 2), 16, 0, 0);
+      }
+    }
+    {  // stores of this item
+      double* out = val + d.vb0;
+      typedef double v2d_t __attribute__((ext_vector_type(2)));
+      const int npair = (nval - sh) >> 1;
+      const v2d_t* src = reinterpret_cast<const v2d_t*>(lds + 2 * sh);
+      v2d_t* dst = reinterpret_cast<v2d_t*>(out + sh);
+      for (int x = threadIdx.x; x < npair; x += BLOCK) __builtin_nontemporal_store(src[x], dst + x);
+      if (sh && threadIdx.x == 0) __builtin_nontemporal_store(sl[0], out);
+      if (((nval - sh) & 1) && threadIdx.x == 64) __builtin_nontemporal_store(sl[nval - 1], out + nval - 1);
+    }
+    if (!more) break;
+    // the LDS reads of the store phase are done before the next item zeroes the slice; raw barrier: __syncthreads()
+    // would drain vmcnt (the stores just issued and the DMA) here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    w = wn; pl = pl2; ax = ax2; d = d2; nt = nt2;
+  }
+}
+
 // ---- persistent, software-pipelined row gather -----------------------------------------------
 // Same arithmetic and LDS accumulation as k_tet4_rg5, but a workgroup loops over work items (w = blockIdx.x,
 // += gridDim.x) and EVERYTHING an item needs arrives by LDS-DMA (global_load_lds: no VGPR destination) while earlier
@@ -783,6 +928,22 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
                      acc_doubles, a.opt_pf)
     if (a.opt_occ == 1) RDC_RG4(1); else RDC_RG4(2);
 #undef RDC_RG4
+    return hipGetLastError();
+  }
+  if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0 &&
+                (std::is_same<M, PihnaNoCellTransportMoments>::value || std::is_same<M, PihnaNoCellTransport>::value))
+  if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 && a.opt_kernel == 6) {
+    constexpr int BLOCK = 256;
+    const int nl = a.rg2.nl_stride;
+    const int acc_doubles = (int)((a.rg2.lds_bytes / sizeof(double) + 3) & ~(size_t)1);
+    const size_t lds_bytes = sizeof(double) * ((size_t)acc_doubles + (size_t)(Rec<M>::N / 2) * nl * 2);
+    const int wg_begin = a.rg2.wg_begin, wg_count = a.rg2.wg_count < 0 ? a.rg2.n_wg - a.rg2.wg_begin : a.rg2.wg_count;
+    if (wg_count <= 0) return hipSuccess;
+    int grid = a.opt_grid > 0 ? a.opt_grid : 512;   // two resident workgroups per CU
+    if (grid > wg_count) grid = wg_count;
+    hipLaunchKernelGGL((k_tet4_rg6<M, EXP_MODE, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, a.stream, a.rg2.desc, a.rg2.pair_loc,
+                       a.rg2.pair_aux, a.rg2.nlist, a.rg2.node_tab, k, a.packed, a.val, a.rhs, nl, acc_doubles, wg_begin,
+                       wg_begin + wg_count);
     return hipGetLastError();
   }
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 &&
