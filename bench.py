@@ -10,7 +10,14 @@ CSR matrix + rhs.  Inputs are resident in HBM when the timed region starts.
 Workload: BASELINE.json's metric is quoted on the 10M-tet PIHNA mesh, which fits one GPU:
 K(119) = 10,110,954 TET4 / 1,728,000 nodes, 5 unknowns (8.64 M DoFs, 648 M CSR values), synthetic
 fields, parameters of run/PIHNA/input.dat.  N > 1 partitions that SAME mesh (strong scaling).
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries
+  "configs"      kernel time / elements per second / roofline fraction of the other BASELINE configurations
+                 (cfg2 PIHNA K(55), cfg3 RIPF K(94), cfg5 HCC H(126) + solid H(126)) and of the general-parameter PIHNA
+                 kernel on K(119), each timed here with HIP events (3 warm-ups + 10 launches);
+  "handback"     the CSR hand-back to the host (SURVEY §8d "kernel + CSR-handback separately"): D2H of values + rhs
+                 into pinned memory, alone, behind the kernel, and overlapped with part 2 of a two-part assembly;
+  "cpu_baseline" the oracle (a port of the reference loop) on 1 and on all host cores.
+At N > 1 it carries "multi_gpu": halo bytes, ghost-element overhead, halo time, host time per step.
 """
 from __future__ import annotations
 
@@ -26,28 +33,197 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6  # vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 
 
-def algorithmic_bytes(nen, n_elem, n_node, n_owned, nvar, n_in, nnz):
-    """SURVEY §8d / BASELINE.md §3: compulsory traffic of one assembly pass (FP64 values, int32 ids)."""
-    return 4 * nen * n_elem + 8 * 3 * n_node + 8 * n_in * n_node + 8 * nnz + 8 * nvar * n_owned
+def algorithmic_bytes(nen, n_elem, n_node, n_owned, nvar, n_in, nnz, solid=False):
+    """SURVEY §8d / BASELINE.md §3: compulsory traffic of one assembly pass (FP64 values, int32 ids).
+    solid: current + undeformed coordinates, 3 fibre + 1 subdomain entries per element, no nodal input fields."""
+    b = 4 * nen * n_elem + 8 * 3 * n_node + 8 * n_in * n_node + 8 * nnz + 8 * nvar * n_owned
+    if solid:
+        b += 8 * 3 * n_node + 8 * 4 * n_elem
+    return b
+
+
+def host_threads():
+    """cores this process may use, capped at the GPU box's share per GPU (16)"""
+    return max(1, min(16, len(os.sched_getaffinity(0))))
 
 
 def cpu_baseline(n_sample, param_variant):
-    """Oracle ("port" of the reference loop + MatSetValues-like insertion) on 1 host core, bounded sample."""
+    """Oracle ("port" of the reference loop + MatSetValues-like insertion), timing build (-O3 -march=native, compiled
+    here), on 1 host core and on all of them (rows split over threads: the stand-in for `mpiexec -n P`)."""
     from oracle import oracle as O
     from rdcfes_amd import pihna_params_from_dict, synth
     conn, xyz = synth.kuhn_tet_mesh(n_sample, order="lex")
     u = synth.pihna_fields(xyz)
     p = pihna_params_from_dict(synth.pihna_param_dict(param_variant))
     pattern = O.build_pattern(4, conn, xyz.shape[0], xyz.shape[0], 5)[:2]
+    O.fast_lib()
+    nt = host_threads()
     t0 = time.perf_counter()
-    O.assemble(O.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern)
-    dt = time.perf_counter() - t0
-    return {"value": conn.shape[0] / dt, "unit": "elements/s", "cores": 1, "kind": "port",
-            "sample": f"K({n_sample}) = {conn.shape[0]} TET4 of the same generator/fields/params, full assembly "
-                      f"incl. sorted-row CSR insertion, {dt:.1f} s on 1 core (oracle/rdc_oracle.c, gcc -O2)"}
+    O.assemble(O.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern, threads=nt, fast=True)
+    dt_all = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.assemble(O.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern, threads=1, fast=True)
+    dt_1 = time.perf_counter() - t0
+    return {"value": conn.shape[0] / dt_all, "unit": "elements/s", "cores": nt, "kind": "port",
+            "value_1core": conn.shape[0] / dt_1,
+            "sample": f"K({n_sample}) = {conn.shape[0]} TET4 of the same generator/fields/params as the benchmark mesh, full assembly "
+                      f"incl. sorted-row CSR insertion: {dt_all:.1f} s on {nt} cores (rows split over OpenMP threads, elements "
+                      f"straddling two ranges evaluated twice), {dt_1:.1f} s on 1 core (oracle/rdc_oracle.c, gcc -O3 -march=native); "
+                      "stand-in for the reference's libMesh/PETSc path, which cannot be built here"}
+
+
+def time_config(name, nen, conn, xyz, nvar, setup, call, n_in, solid=False, reps=10, warm=3, note=None):
+    """kernel time of one configuration with HIP events on the context stream -> dict for the "configs" array"""
+    from rdcfes_amd import AssemblyContext
+    with AssemblyContext(0) as ctx:
+        t0 = time.perf_counter()
+        ctx.mesh_upload(nen, conn, xyz, nvar)
+        prep_s = time.perf_counter() - t0
+        setup(ctx)
+        for _ in range(warm):
+            call(ctx)
+        ctx.synchronize()
+        ctx.timing_enable(True)
+        for _ in range(reps):
+            call(ctx)
+        ms, n = ctx.timing_sum_ms()
+        ctx.timing_enable(False)
+        ms /= max(n, 1)
+        _, nnz = ctx.csr_dims()
+    b = algorithmic_bytes(nen, conn.shape[0], xyz.shape[0], xyz.shape[0], nvar, n_in, nnz, solid)
+    out = {"workload": name, "elements": int(conn.shape[0]), "nodes": int(xyz.shape[0]), "nnz": int(nnz),
+           "kernel_ms": ms, "elements_per_s": conn.shape[0] / (ms * 1e-3), "algorithmic_bytes_per_launch": int(b),
+           "achieved_GBps": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches_timed": int(n),
+           "host_prep_s": round(prep_s, 2)}
+    if note:
+        out["note"] = note
+    return out
+
+
+def extra_configs():
+    """the BASELINE configurations beside the headline one, each at its stated size (SURVEY §8d synthetic inputs)"""
+    from rdcfes_amd import (SolidMaterial, SolidParams, hcc_params_from_dict, pihna_params_from_dict, ripf_params_from_dict, synth)
+    from rdcfes_amd.context import FIELD_AUX_NODAL, FIELD_ELEM_FIBRE, FIELD_OLD_SOLUTION, FIELD_UNDEFORMED_XYZ
+    out = []
+    # cfg2: PIHNA, 1M TET4
+    conn, xyz = synth.kuhn_tet_mesh(55, order="lex")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    out.append(time_config("cfg2: PIHNA TET4 K(55), params run/PIHNA/input.dat", 4, conn, xyz, 5,
+                           lambda c: c.field_upload(FIELD_OLD_SOLUTION, u), lambda c: c.assemble_pihna(p), 5))
+    # general-parameter PIHNA kernel on the metric's mesh (every transport term on: no parameter-pattern variant applies)
+    conn, xyz = synth.kuhn_tet_mesh(119, order="lex")
+    u = synth.pihna_fields(xyz)
+    pf = pihna_params_from_dict(synth.pihna_param_dict("full"))
+    out.append(time_config("PIHNA TET4 K(119), all transport terms non-zero (general instantiation)", 4, conn, xyz, 5,
+                           lambda c: c.field_upload(FIELD_OLD_SOLUTION, u), lambda c: c.assemble_pihna(pf), 5))
+    # cfg3: RIPF, 5M TET4
+    conn, xyz = synth.kuhn_tet_mesh(94, order="lex")
+    u, aux = synth.ripf_fields(xyz)
+
+    def setup_ripf(c):
+        c.field_upload(FIELD_OLD_SOLUTION, u)
+        c.field_upload(FIELD_AUX_NODAL, aux)
+    for pv in ("shipped", "full"):
+        pr = ripf_params_from_dict(synth.ripf_param_dict(pv))
+        out.append(time_config(f"cfg3: RIPF TET4 K(94), params run/RIPF133/input.dat ({pv})", 4, conn, xyz, 3, setup_ripf,
+                               lambda c: c.assemble_ripf(pr), 6))
+    # cfg5: coupled HCC + solid, 2M HEX8 (one reaction-diffusion assembly on the deformed mesh, one Newton assembly)
+    conn, Xu = synth.hex_mesh(126, jitter=0.1, order="lex")
+    x = Xu + synth.solid_displacement(Xu, amp=0.02 / 126 * 8)
+    uh = synth.hcc_fields(Xu)
+    ph = hcc_params_from_dict(synth.hcc_param_dict("full"))
+    out.append(time_config("cfg5 (RD half): HCC HEX8 H(126) on the deformed mesh, all rates non-zero", 8, conn, x, 3,
+                           lambda c: c.field_upload(FIELD_OLD_SOLUTION, uh), lambda c: c.assemble_hcc(ph), 3, reps=6))
+    em = (np.linalg.norm(Xu[conn].mean(axis=1) - 0.5, axis=1) < 0.3).astype(np.int32)
+    mats = [SolidMaterial(2.0e3, 0.4, 0.0, (0.0, 0.0, 0.0)), SolidMaterial(2.0e3, 0.4, 0.0, (0.3, 0.3, 0.3))]
+    se0, ss0 = synth.boundary_sides(8, conn, Xu, 2, 0.0)
+    sd = np.zeros((se0.size, 3))
+    sp = SolidParams(0.4, 1.0e8, 0, 0)
+    fibre = np.tile([0.0, 0.0, 1.0], (conn.shape[0], 1))
+
+    def setup_solid(c):
+        c.field_upload(FIELD_UNDEFORMED_XYZ, Xu)
+        c.field_upload(FIELD_ELEM_FIBRE, fibre)
+        c.solid_set_materials(em, mats)
+        c.solid_set_sides(se0, ss0, sd)
+    out.append(time_config("cfg5 (solid half): SolidSystem HEX8 H(126), residual + Jacobian of one Newton iteration", 8, conn, x, 3,
+                           setup_solid, lambda c: c.solid_assemble(sp, True), 0, solid=True, reps=6,
+                           note="FP64-compute-bound path (SURVEY §8d): frac is against the HBM roof for completeness"))
+    return out
+
+
+def handback(ctx, assemble, n_owned, nnz, n_rows, kern_ms, reps=3):
+    """CSR hand-back to the host (the reference hands its blocks to PETSc, src/pihna.C:754-755): D2H of values + rhs."""
+    import torch
+    val_h = torch.empty(nnz, dtype=torch.float64, pin_memory=True)
+    rhs_h = torch.empty(n_rows, dtype=torch.float64, pin_memory=True)
+    main_s = torch.cuda.current_stream()
+    copy_s = torch.cuda.Stream()
+    ctx.set_option("part", 0)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        fn()  # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def copy_only():
+        ctx.csr_download_rows(0, n_owned, val_h.data_ptr(), rhs_h.data_ptr(), asynchronous=True)
+
+    def serial():
+        assemble()
+        ctx.csr_download_rows(0, n_owned, val_h.data_ptr(), rhs_h.data_ptr(), asynchronous=True)
+
+    # overlapped: rows of the first half of the nodes are copied while the second half is being assembled
+    ctx.set_option("interior_nodes", n_owned // 2)
+    n1 = ctx.part1_nodes()
+
+    def overlapped():
+        ctx.set_option("part", 1)
+        assemble()
+        copy_s.wait_stream(main_s)
+        ctx.set_stream(copy_s.cuda_stream)
+        ctx.csr_download_rows(0, n1, val_h.data_ptr(), rhs_h.data_ptr(), asynchronous=True)
+        ctx.set_stream(main_s.cuda_stream)
+        ctx.set_option("part", 2)
+        assemble()
+        ctx.set_option("part", 0)
+        main_s.wait_stream(copy_s)   # one copy engine direction: keep the two transfers in order
+        ctx.csr_download_rows(n1, n_owned, val_h.data_ptr(), rhs_h.data_ptr(), asynchronous=True)
+
+    d2h = timed(copy_only)
+    ser = timed(serial)
+    ovl = timed(overlapped) if n1 > 0 else None
+    ctx.set_option("part", 0)
+    ctx.set_option("interior_nodes", -1)
+    nbytes = 8 * (nnz + n_rows)
+    return {"bytes": int(nbytes), "d2h_ms": d2h, "d2h_GBps": nbytes / d2h / 1e6, "kernel_ms": kern_ms,
+            "kernel_plus_handback_ms": ser, "kernel_plus_handback_overlapped_ms": ovl,
+            "note": "host wall time per step, pinned host buffers, rdc_csr_download_rows; the device-pointer hand-off "
+                    "(rdc_csr_values_device_ptr) avoids this copy altogether"}
+
+
+def profile_numbers(n, world):
+    """HBM bytes and FP64 flops per launch from the committed rocprofv3 --pmc passes -- only if they were taken from
+    the kernel sources that are built now (profiles/pmc_traffic.json carries their hash), else null."""
+    from rdcfes_amd import build as B
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        t = json.loads(pmc.read_text())
+        if t.get("workload") == f"K({n})" and t.get("n_gpus") == world and t.get("source_hash") == B.source_hash():
+            return t.get("hbm_bytes_per_launch"), t.get("fp64_flop_per_launch"), t.get("kernel")
+    except Exception:
+        pass
+    return None, None, None
 
 
 def main():
@@ -65,6 +241,8 @@ def main():
                     help="nccl = RCCL over xGMI (production); gloo = host-staged halo, for rehearsing N > 1 on a 1-GPU box")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (rdc_set_option)")
     ap.add_argument("--cpu-sample", type=int, default=84, help="K(m) sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--configs", type=int, default=1, help="N = 1: also time the other BASELINE configurations (0 = skip)")
+    ap.add_argument("--handback", type=int, default=1, help="N = 1: also time the CSR hand-back to the host (0 = skip)")
     a = ap.parse_args()
 
     import torch
@@ -119,7 +297,8 @@ def main():
 
     # N > 1: the halo exchange runs on a side stream while the rows of interior nodes (no ghost node in any of their
     # elements; partition.build_local numbers them first) are assembled on the main stream; the remaining rows follow
-    # the exchange on its stream (tools/two_part_ab.py: the split itself costs ~13 us per step at per-GPU size)
+    # the exchange on its stream (tools/two_part_ab.py: the split itself costs ~13 us per step at per-GPU size).
+    # Stream contract of the two parts: include/rdc_assembly.h ("part").
     overlap = hx is not None and a.overlap and lp.n_interior > 0
     if overlap:
         main_s, halo_s = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
@@ -154,31 +333,45 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_host = time.perf_counter() - t0       # host time to ENQUEUE the steps (no device wait inside step())
     fence()
     dt = time.perf_counter() - t0
     kern_ms, n_calls = ctx.timing_sum_ms()
     ctx.timing_enable(False)
+    multi = None
     if world > 1:
-        t = torch.tensor([dt, kern_ms / max(n_calls, 1)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        if overlap:
-            t[1] = kern_ms / a.steps        # two launches per step
+        # diagnostics of the N > 1 run: the exchange alone (device time between events on this rank's stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        e0.record()
+        for _ in range(a.steps):
+            hx.exchange(u_t)
+        e1.record()
+        fence()
+        halo_ms = e0.elapsed_time(e1) / a.steps
+        on_cpu = a.backend != "nccl"
+        t = torch.tensor([dt, kern_ms / max(n_calls, 1) if not overlap else kern_ms / a.steps, halo_ms, t_host / a.steps * 1e6,
+                          float(hx.bytes_per_step), float(l_conn.shape[0]) / max(lp.n_elem_owned, 1), float(len(hx.peers))],
+                         dtype=torch.float64, device="cpu" if on_cpu else dev)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dt, kern_avg_ms = float(t[0]), float(t[1])
+        multi = {"halo_ms_max": float(t[2]), "halo_ms_min": float(tmin[2]), "host_enqueue_us_per_step_max": float(t[3]),
+                 "halo_send_bytes_per_rank_max": float(t[4]), "halo_send_bytes_per_rank_min": float(tmin[4]),
+                 "local_over_owned_elements_max": float(t[5]), "local_over_owned_elements_min": float(tmin[5]),
+                 "peers_max": int(t[6]), "kernel_ms_per_step_max": float(t[1]), "kernel_ms_per_step_min": float(tmin[1]),
+                 "interior_node_fraction_rank0": lp.n_interior / max(lp.n_owned, 1),
+                 "note": "halo_ms = grouped isend/irecv round alone, back to back; kernel_ms = HIP events around the assembly "
+                         "kernel(s) of a step; local_over_owned_elements = (partition + ghost layer) / partition"}
     else:
         kern_avg_ms = kern_ms / max(n_calls, 1)
 
     if rank == 0:
         b_alg = algorithmic_bytes(4, l_conn.shape[0], l_xyz.shape[0], n_owned, 5, 5, nnz)
         achieved = b_alg / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"  # written from rocprofv3 --pmc passes, see profiles/README.md
-        if pmc.exists():
-            try:
-                t = json.loads(pmc.read_text())
-                if t.get("workload") == f"K({a.n})" and t.get("n_gpus") == world:
-                    traffic = t.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, flop, prof_kernel = profile_numbers(a.n, world) if a.params == "shipped" and not a.opt else (None, None, None)
+        fp64_tflops = flop / (kern_avg_ms * 1e-3) / 1e12 if flop else None
         out = {
             "metric": "elements_assembled_per_sec", "value": n_elem_global * a.steps / dt, "unit": "elements/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -190,12 +383,28 @@ def main():
                        "rank0_local_elements": int(l_conn.shape[0]), "rank0_nnz": int(nnz)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": kern_avg_ms},
+                         "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": kern_avg_ms,
+                         "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+                         "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS if fp64_tflops else None,
+                         "profile_kernel": prof_kernel,
+                         "note": "traffic / fp64_* come from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json) and are "
+                                 "null unless that profile was taken from the kernel sources built now"},
         }
-        if world == 1 and a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.params)
-        print(json.dumps(out), flush=True)
+        if multi:
+            out["multi_gpu"] = multi
+        if world == 1:
+            if a.handback:
+                out["handback"] = handback(ctx, lambda: ctx.assemble_pihna(p), n_owned, nnz, n_rows, kern_avg_ms)
     ctx.close()
+    del u_t
+    if rank == 0 and world == 1:
+        torch.cuda.empty_cache()
+        if a.configs:
+            out["configs"] = extra_configs()
+        if a.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.params)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -197,7 +197,12 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * its owned nodes interior-first); with "part" = 1 an assemble call then writes only the rows of leading workgroups
  * inside [0, n), with "part" = 2 the remaining rows, with "part" = 0 (default) all rows.  Part 1 followed by part 2
  * gives exactly the matrix and residual of one whole call.  Paths that cannot launch sub-ranges (HEX8, the
- * coloured strategy, the solid system) write nothing in part 1 and everything in part 2. */
+ * coloured strategy, the solid system) write nothing in part 1 and everything in part 2.
+ * Stream contract: part 1 and part 2 of a step may be issued on DIFFERENT streams (rdc_set_stream in between).  Part 1
+ * reads the values of owned nodes only, so the ghost rows of the bound fields may be rewritten (halo exchange)
+ * while it runs; part 2 must be issued behind that exchange on its stream.  The library itself orders part 2 behind
+ * part 1's preparation of the owned node data (an internal event), and neither part writes data the other may be
+ * reading.  The caller orders the NEXT step's exchange behind this step's part 2 (it reads the ghost rows). */
 int rdc_set_option(rdc_ctx* ctx, const char* key, int value);
 
 /* ---- mesh / pattern (one-time set-up; replaces es.init()) ---- */
@@ -251,6 +256,14 @@ int rdc_solid_assemble(rdc_ctx* ctx, const rdc_solid_params* p, int request_jaco
 /* ---- results ---- */
 int rdc_csr_values_device_ptr(rdc_ctx* ctx, double** d_val, double** d_rhs);
 int rdc_csr_download(rdc_ctx* ctx, double* val, double* rhs);
+/* Chunked hand-back: the CSR values and rhs entries of the rows of nodes [node_begin, node_end) only, written to the
+ * SAME positions of the full-size host arrays val / rhs as rdc_csr_download uses (either may be NULL).  async != 0:
+ * the copies are only enqueued on the context's stream (use pinned host memory; complete after rdc_synchronize or an
+ * event of the caller) -- so the rows of part 1 of a two-part assembly can travel while part 2 is still computing. */
+int rdc_csr_download_rows(rdc_ctx* ctx, int64_t node_begin, int64_t node_end, double* val, double* rhs, int async);
+/* two-part assembly: the rows of nodes [0, *n_nodes) are the ones "part" = 1 writes with the current
+ * "interior_nodes" (whole workgroups inside the interior; 0 when the active path cannot launch sub-ranges) */
+int rdc_part1_nodes(const rdc_ctx* ctx, int64_t* n_nodes);
 
 /* ---- post-solve nodal kernel: negativity clamp of check_solution,
  * src/pihna.C:785-790, applied in place to a device-resident field ---- */

@@ -14,7 +14,9 @@ from rdcfes_amd.params import HccParams, PihnaParams, RipfParams, SolidMaterial,
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "librdc_oracle.so"
 MODEL_PIHNA, MODEL_RIPF, MODEL_HCC, MODEL_SOLID, MODEL_ADPM, MODEL_PROTEAS = 0, 1, 2, 3, 4, 5
+FAST_LIB = HERE / "_fast" / "librdc_oracle_fast.so"
 _lib = None
+_fast = None
 
 
 def build(force=False):
@@ -31,6 +33,16 @@ def lib():
         _lib = C.CDLL(str(LIB))
         _lib.oracle_build_node_pattern.restype = C.c_int64
     return _lib
+
+
+def fast_lib():
+    """The timing build (-O3 -march=native, oracle/Makefile) for bench.py's cpu_baseline: always rebuilt on the
+    machine it runs on (never shipped: -march=native code is only valid where it was compiled)."""
+    global _fast
+    if _fast is None:
+        subprocess.run(["make", "-C", str(HERE), "-B", "_fast/librdc_oracle_fast.so"], check=True, capture_output=True)
+        _fast = C.CDLL(str(FAST_LIB))
+    return _fast
 
 
 def _p(a, t=C.c_double):
@@ -126,8 +138,10 @@ def build_pattern(elem_type, conn, n_node, n_owned, nvar):
 
 def assemble(model, elem_type, conn, xyz, nvar, params, u_old=None, aux=None, n_owned=None, xyz_undeformed=None,
              elem_fibre=None, elem_material=None, materials=None, request_jacobian=True, pattern=None,
-             e_begin=0, e_end=None, sides=None):
-    """Reference-order whole-mesh assembly (elements [e_begin,e_end)).  Returns (row_ptr, col, val, rhs)."""
+             e_begin=0, e_end=None, sides=None, threads=1, fast=False):
+    """Reference-order whole-mesh assembly (elements [e_begin,e_end)).  Returns (row_ptr, col, val, rhs).
+    threads > 1: rows split over host cores (oracle_assemble_mt, bitwise equal to the serial loop);
+    fast: the -O3 -march=native timing build (cpu_baseline only)."""
     conn = np.ascontiguousarray(conn, dtype=np.uint32)
     xyz = np.ascontiguousarray(xyz, dtype=np.float64)
     n_node = xyz.shape[0]
@@ -143,10 +157,11 @@ def assemble(model, elem_type, conn, xyz, nvar, params, u_old=None, aux=None, n_
     u_old, aux, xyz_undeformed, elem_fibre = cu(u_old), cu(aux), cu(xyz_undeformed), cu(elem_fibre)
     em = None if elem_material is None else np.ascontiguousarray(elem_material, dtype=np.int32)
     mats = None if materials is None else (SolidMaterial * len(materials))(*materials)
-    rc = lib().oracle_assemble(int(model), int(elem_type), C.c_int64(e_begin), C.c_int64(e_end), C.c_int64(n_owned),
-                               _p(conn, C.c_uint32), _p(xyz), int(nvar), _p(u_old), _p(aux), _p(xyz_undeformed),
-                               _p(elem_fibre), _p(em, C.c_int32), mats, C.byref(params), int(request_jacobian),
-                               _p(row_ptr, C.c_int64), _p(col, C.c_int32), _p(val), _p(rhs))
+    L = fast_lib() if fast else lib()
+    rc = L.oracle_assemble_mt(int(threads), int(model), int(elem_type), C.c_int64(e_begin), C.c_int64(e_end), C.c_int64(n_owned),
+                              _p(conn, C.c_uint32), _p(xyz), int(nvar), _p(u_old), _p(aux), _p(xyz_undeformed),
+                              _p(elem_fibre), _p(em, C.c_int32), mats, C.byref(params), int(request_jacobian),
+                              _p(row_ptr, C.c_int64), _p(col, C.c_int32), _p(val), _p(rhs))
     assert rc == 0, rc
     if sides is not None:
         se, si, sd = sides

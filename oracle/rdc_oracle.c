@@ -487,7 +487,7 @@ static void hyper_calculate_stress(hyper_state* S, double Young, double Poisson,
   const double d2WdI1dI1 = 0.0, d2WdI2dI2 = 0.0, d2WdI4dI4 = 0.0;
   const double d2WdJedJe = (mu / Je / Je) + (lambda / 2.0 + lambda / 2.0 / Je / Je);
   double dI1[3][3], dI2[3][3], dJe[3][3], dI4[3][3];
-  static double d2I2[3][3][3][3], d2Je[3][3][3][3]; /* not re-entrant: oracle is single-threaded */
+  double d2I2[3][3][3][3], d2Je[3][3][3][3]; /* on the stack: oracle_assemble_mt calls this from several threads */
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       dI1[i][j] = delta[i][j];
@@ -514,7 +514,7 @@ static void hyper_calculate_stress(hyper_state* S, double Young, double Poisson,
       S->sigma[i][j] = s * J_recip;
     }
   if (!tangent) return;
-  static double dSdCe[3][3][3][3], dCedC[3][3][3][3], dSdC[3][3][3][3], tsm[3][3][3][3];
+  double dSdCe[3][3][3][3], dCedC[3][3][3][3], dSdC[3][3][3][3], tsm[3][3][3][3];
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++)
       for (int k = 0; k < 3; k++)
@@ -1104,12 +1104,16 @@ static inline void csr_add(const int64_t* row_ptr, const int32_t* col_idx, doubl
 
 /* Whole-mesh assembly = the reference callback.  model: 0 PIHNA, 1 RIPF, 2 HCC, 3 SOLID.
  * Elements [e_begin, e_end) only (lets the CPU baseline time a bounded sample). */
-int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, int64_t n_owned,
-                    const uint32_t* conn, const double* xyz, int nvar, const double* u_old,
-                    const double* aux_nodal, const double* xyz_undeformed, const double* elem_fibre,
-                    const int32_t* elem_material, const rdc_solid_material* materials,
-                    const void* params, int request_jacobian, const int64_t* row_ptr,
-                    const int32_t* col_idx, double* val, double* rhs) {
+/* The element loop over [e_begin, e_end) restricted to the rows of nodes [node_lo, node_hi): elements without a
+ * node in that range are skipped, the others are evaluated completely and only those rows are inserted.  With
+ * [0, n_owned) this is the reference loop.  A row receives its contributions in ascending element order whatever
+ * the range is, so splitting the rows over threads (oracle_assemble_mt) reproduces the serial result bit for bit. */
+static int assemble_rows(int model, int elem_type, int64_t e_begin, int64_t e_end, int64_t node_lo, int64_t node_hi,
+                         const uint32_t* conn, const double* xyz, int nvar, const double* u_old,
+                         const double* aux_nodal, const double* xyz_undeformed, const double* elem_fibre,
+                         const int32_t* elem_material, const rdc_solid_material* materials,
+                         const void* params, int request_jacobian, const int64_t* row_ptr,
+                         const int32_t* col_idx, double* val, double* rhs) {
   const int nen = elem_type, nqp = oracle_nqp(elem_type);
   if (nqp < 0) return 1;
   const int nd = nvar * nen;
@@ -1118,6 +1122,11 @@ int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, in
   double* Fe = (double*)malloc(sizeof(double) * nd);
   for (int64_t e = e_begin; e < e_end; e++) {
     const uint32_t* c = conn + e * nen;
+    {
+      int any = 0;
+      for (int i = 0; i < nen; i++) any |= ((int64_t)c[i] >= node_lo && (int64_t)c[i] < node_hi);
+      if (!any) continue;
+    }
     for (int i = 0; i < nen; i++) {
       for (int d = 0; d < 3; d++) X[3 * i + d] = xyz[3 * (int64_t)c[i] + d];
       if (u_old) for (int a = 0; a < nvar; a++) U[nvar * i + a] = u_old[(int64_t)c[i] * nvar + a];
@@ -1145,7 +1154,7 @@ int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, in
     /* add_matrix / add_vector, src/pihna.C:754-755 (constraints are the identity here) */
     for (int a = 0; a < nvar; a++)
       for (int i = 0; i < nen; i++) {
-        if ((int64_t)c[i] >= n_owned) continue; /* row owned elsewhere */
+        if ((int64_t)c[i] < node_lo || (int64_t)c[i] >= node_hi) continue; /* row owned elsewhere */
         const int64_t row = (int64_t)c[i] * nvar + a;
         rhs[row] += Fe[a * nen + i];
         if (model == 3 && !request_jacobian) continue;
@@ -1156,6 +1165,63 @@ int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, in
   }
   free(Ke); free(Fe);
   return 0;
+}
+
+int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, int64_t n_owned,
+                    const uint32_t* conn, const double* xyz, int nvar, const double* u_old,
+                    const double* aux_nodal, const double* xyz_undeformed, const double* elem_fibre,
+                    const int32_t* elem_material, const rdc_solid_material* materials,
+                    const void* params, int request_jacobian, const int64_t* row_ptr,
+                    const int32_t* col_idx, double* val, double* rhs) {
+  return assemble_rows(model, elem_type, e_begin, e_end, 0, n_owned, conn, xyz, nvar, u_old, aux_nodal, xyz_undeformed,
+                       elem_fibre, elem_material, materials, params, request_jacobian, row_ptr, col_idx, val, rhs);
+}
+
+/* The same on n_threads host cores: thread t owns the rows of a contiguous node range (ranges balanced by CSR
+ * values) and runs the element loop for them -- the stand-in for the reference's `mpiexec -n P` (run/PIHNA/Makefile:8),
+ * where every rank loops over its own partition.  Elements straddling two ranges are evaluated by both threads
+ * (the reference exchanges such rows through PETSc's stash instead).  Bitwise equal to oracle_assemble. */
+int oracle_assemble_mt(int n_threads, int model, int elem_type, int64_t e_begin, int64_t e_end, int64_t n_owned,
+                       const uint32_t* conn, const double* xyz, int nvar, const double* u_old,
+                       const double* aux_nodal, const double* xyz_undeformed, const double* elem_fibre,
+                       const int32_t* elem_material, const rdc_solid_material* materials,
+                       const void* params, int request_jacobian, const int64_t* row_ptr,
+                       const int32_t* col_idx, double* val, double* rhs) {
+  if (n_threads < 1) n_threads = 1;
+  int64_t* cut = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_threads + 1));
+  /* rows the element range can touch: [lo, hi) */
+  int64_t lo = n_owned, hi = 0;
+  for (int64_t x = e_begin * elem_type; x < e_end * elem_type; x++) {
+    const int64_t n = conn[x];
+    if (n >= n_owned) continue;
+    if (n < lo) lo = n;
+    if (n + 1 > hi) hi = n + 1;
+  }
+  if (lo > hi) lo = hi;
+  const int64_t v0 = row_ptr[lo * nvar], nnz = row_ptr[hi * nvar] - v0;
+  cut[0] = 0;
+  {
+    int64_t n = lo;
+    for (int t = 1; t < n_threads; t++) {
+      const int64_t target = v0 + nnz / n_threads * t;
+      while (n < hi && row_ptr[n * nvar] < target) n++;
+      cut[t] = n;
+    }
+  }
+  cut[n_threads] = n_owned;
+  int rc_all = 0;
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+  for (int t = 0; t < n_threads; t++) {
+    const int rc = assemble_rows(model, elem_type, e_begin, e_end, cut[t], cut[t + 1], conn, xyz, nvar, u_old, aux_nodal,
+                                 xyz_undeformed, elem_fibre, elem_material, materials, params, request_jacobian, row_ptr,
+                                 col_idx, val, rhs);
+    if (rc) {
+#pragma omp atomic write
+      rc_all = rc;
+    }
+  }
+  free(cut);
+  return rc_all;
 }
 
 /* boundary sides of the solid system, added after the element loop (FEMSystem::assembly order) */

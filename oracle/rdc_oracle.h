@@ -31,6 +31,13 @@ int oracle_assemble(int model, int elem_type, int64_t e_begin, int64_t e_end, in
                     const int32_t* elem_material, const rdc_solid_material* materials,
                     const void* params, int request_jacobian, const int64_t* row_ptr,
                     const int32_t* col_idx, double* val, double* rhs);
+/* oracle_assemble on n_threads host cores (rows split over threads; bitwise equal to the serial loop) */
+int oracle_assemble_mt(int n_threads, int model, int elem_type, int64_t e_begin, int64_t e_end, int64_t n_owned,
+                       const uint32_t* conn, const double* xyz, int nvar, const double* u_old,
+                       const double* aux_nodal, const double* xyz_undeformed, const double* elem_fibre,
+                       const int32_t* elem_material, const rdc_solid_material* materials,
+                       const void* params, int request_jacobian, const int64_t* row_ptr,
+                       const int32_t* col_idx, double* val, double* rhs);
 int oracle_assemble_solid_sides(int elem_type, int64_t n_sides, const int64_t* side_elem,
                                 const int32_t* side_id, const double* side_disp, int64_t n_owned,
                                 const uint32_t* conn, const double* xyz, const double* xyz_undeformed,

@@ -49,6 +49,17 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources: ties a committed profile (profiles/pmc_traffic.json) to the code it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(CSRC.glob("*")):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _newest_dep() -> float:
     deps = list(CSRC.glob("*")) + [ROOT.parent / "include" / "rdc_assembly.h", Path(__file__)]
     return max(p.stat().st_mtime for p in deps)

@@ -232,6 +232,16 @@ class AssemblyContext:
         self._ck(self._lib.rdc_csr_download(self._h, _dp(val) if want_val else None, _dp(rhs) if want_rhs else None))
         return val, rhs
 
+    def csr_download_rows(self, node_begin, node_end, val_ptr, rhs_ptr, asynchronous=False):
+        """rows of nodes [node_begin, node_end) into full-size host arrays given by ADDRESS (e.g. pinned torch tensors)"""
+        self._ck(self._lib.rdc_csr_download_rows(self._h, int(node_begin), int(node_end), C.c_void_p(int(val_ptr) if val_ptr else None),
+                                                 C.c_void_p(int(rhs_ptr) if rhs_ptr else None), 1 if asynchronous else 0))
+
+    def part1_nodes(self):
+        n = C.c_int64()
+        self._ck(self._lib.rdc_part1_nodes(self._h, C.byref(n)))
+        return n.value
+
     # -- instrumentation
     def timing_enable(self, on=True):
         self._ck(self._lib.rdc_timing_enable(self._h, 1 if on else 0))

@@ -39,6 +39,8 @@ struct rdc_ctx {
   int opt_special = 1;  // allow parameter-sparsity kernel variants
   int opt_part = 0;            // 0 = whole mesh, 1 = workgroups of interior nodes only, 2 = the remaining workgroups
   int64_t opt_interior = -1;   // owned nodes [0, opt_interior) have no ghost node in any of their elements
+  hipEvent_t pack_event = nullptr;  // two-part assembly: recorded behind part 1's pack of the owned node records
+  bool part1_packed = false;        // part 1 of the current step has packed the owned records (consumed by part 2)
   int opt_stagger = 0;
   int opt_ldspad = 0;
   int opt_moments = 1;  // PIHNA (cell transport off) TET4: moment form of the rows
@@ -223,6 +225,16 @@ hipError_t launch_specialised<Adpm, rdc_adpm_params>(const LaunchArgs& a, const 
   return launch_rd<Adpm>(a, k);
 }
 
+// two-part assembly: number of leading row-gather workgroups whose nodes all lie inside [0, interior_nodes)
+int part1_workgroups(const rdc_ctx* c) {
+  int lo = 0, hi = (int)c->prep.wg2.size();
+  while (lo < hi) {
+    const int mid = (lo + hi) / 2;
+    if ((int64_t)c->prep.wg2[(size_t)mid].n0 + c->prep.wg2[(size_t)mid].nnodes <= c->opt_interior) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 template <class M, class P>
 int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (!c) return RDC_ERR_INVALID;
@@ -299,21 +311,23 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     const bool sub = a.nen == 4 && a.strategy == RDC_SCATTER_ROWGATHER && a.variant != RDC_VARIANT_GENERIC && a.rg2.n_wg > 0 &&
                      a.rg2.pair_aux && a.rg2.nlist && a.rg2.block == 256 && a.opt_kernel == 0 && c->opt_interior >= 0 &&
                      ((M::NELEM == 0 && M::AUX_LOCAL_NODE < 0) || a.rg2.pair_eid);
-    int split = 0;
-    if (sub) {
-      int lo = 0, hi = a.rg2.n_wg;  // first workgroup reaching beyond the interior nodes
-      while (lo < hi) {
-        const int mid = (lo + hi) / 2;
-        if ((int64_t)c->prep.wg2[(size_t)mid].n0 + c->prep.wg2[(size_t)mid].nnodes <= c->opt_interior) lo = mid + 1; else hi = mid;
-      }
-      split = lo;
-    }
+    const int split = sub ? part1_workgroups(c) : 0;
     if (c->opt_part == 1) {
+      c->part1_packed = false;
       if (!sub || split == 0) return RDC_OK;
       a.rg2.wg_begin = 0; a.rg2.wg_count = split;
+      // part 1 packs the records of the owned nodes only and part 2 those of the ghosts, ordered by an event: the two
+      // parts may run on different streams (rdc_assembly.h, stream contract of the two-part assembly)
+      if (!c->pack_event) RDC_HIP(c, hipEventCreateWithFlags(&c->pack_event, hipEventDisableTiming));
+      a.pack_part = 1; a.pack_event = c->pack_event;
+      c->part1_packed = true;
     } else {
       a.rg2.wg_begin = split; a.rg2.wg_count = -1;
+      if (sub && c->part1_packed) { a.pack_part = 2; a.pack_event = c->pack_event; }
+      c->part1_packed = false;
     }
+  } else {
+    c->part1_packed = false;
   }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
@@ -378,6 +392,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->pack_event) (void)hipEventDestroy(c->pack_event);
   delete c;
   return RDC_OK;
 }
@@ -772,6 +787,33 @@ int rdc_csr_download(rdc_ctx* c, double* val, double* rhs) {
   if (val) RDC_HIP(c, hipMemcpyAsync(val, c->val.p, nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (rhs) RDC_HIP(c, hipMemcpyAsync(rhs, c->rhs.p, (size_t)c->prep.n_owned * c->prep.nvar * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_csr_download_rows(rdc_ctx* c, int64_t node_begin, int64_t node_end, double* val, double* rhs, int async) {
+  if (!c) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (node_begin < 0 || node_end < node_begin || node_end > c->prep.n_owned) return fail(c, RDC_ERR_INVALID, "bad node range");
+  int rc = set_device(c);
+  if (rc) return rc;
+  const int64_t nv = c->prep.nvar;
+  const int64_t v0 = nv * nv * c->prep.bptr[(size_t)node_begin], v1 = nv * nv * c->prep.bptr[(size_t)node_end];
+  if (val && v1 > v0)
+    RDC_HIP(c, hipMemcpyAsync(val + v0, (const double*)c->val.p + v0, (size_t)(v1 - v0) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (rhs && node_end > node_begin)
+    RDC_HIP(c, hipMemcpyAsync(rhs + node_begin * nv, (const double*)c->rhs.p + node_begin * nv,
+                              (size_t)((node_end - node_begin) * nv) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (!async) RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_part1_nodes(const rdc_ctx* c, int64_t* n_nodes) {
+  if (!c || !n_nodes) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return RDC_ERR_STATE;
+  *n_nodes = 0;
+  if (c->opt_interior < 0 || !c->prep.rg2_ok || c->prep.nen != 4 || c->prep.wg2.empty()) return RDC_OK;
+  const int split = part1_workgroups(c);
+  if (split > 0) *n_nodes = (int64_t)c->prep.wg2[(size_t)split - 1].n0 + c->prep.wg2[(size_t)split - 1].nnodes;
   return RDC_OK;
 }
 

@@ -47,6 +47,8 @@ struct LaunchArgs {
   int opt_staged = 1;
   const double* elem = nullptr;  // per-element inputs ([n_elem][M::NELEM]) of models that have them (ADPM tracts)
   double* packed;  // scratch for the per-node records of the TET4 fast path
+  int pack_part = 0;               // 0 = pack every record; 1 = owned nodes only, then record pack_event; 2 = wait for pack_event, ghosts only
+  hipEvent_t pack_event = nullptr;
   int variant;     // RDC_VARIANT_*
   int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf, opt_slim = 0, opt_moments = 1, opt_stagger = 0, opt_ldspad = 0;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;

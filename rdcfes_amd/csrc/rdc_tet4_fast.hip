@@ -20,12 +20,13 @@ template <class M> struct Rec {
   static constexpr int N = (RAW + 1) & ~1;  // doubles per node record, even => 16-byte aligned
 };
 
+// records of nodes [node_begin, node_end)
 template <class M>
-__global__ void k_pack_nodes(int64_t n_node, const double* __restrict__ xyz, const double* __restrict__ u,
+__global__ void k_pack_nodes(int64_t node_begin, int64_t node_end, const double* __restrict__ xyz, const double* __restrict__ u,
                              const double* __restrict__ aux, double* __restrict__ rec) {
   constexpr int N = Rec<M>::N, NV = M::NV, NA = M::NAUX;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_node * N; t += stride) {
+  for (int64_t t = node_begin * N + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < node_end * N; t += stride) {
     const int64_t n = t / N;
     const int c = (int)(t - n * N);
     double v = 0.0;
@@ -901,13 +902,22 @@ k_tet4_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t c
 
 template <class M, int EXP_MODE>
 static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) {
+  // Node records.  Two-part assembly (rdc_assembly.h, "part"): part 1 packs only the OWNED nodes -- its rows read
+  // nothing else, and the ghost rows of u may be being rewritten by the halo exchange on another stream -- and
+  // records an event; part 2 (possibly on another stream) waits for that event, packs only the GHOST nodes and then
+  // reads both.  No record is written while a kernel of the other part may read it.
   {
-    const int64_t total = a.m.n_node * Rec<M>::N;
-    int64_t grid = (total + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, a.m.n_node, a.m.xyz, a.u, a.aux,
-                       a.packed);
+    int64_t nb = 0, ne = a.m.n_node;
+    if (a.pack_part == 1) ne = a.m.n_owned;
+    else if (a.pack_part == 2) { nb = a.m.n_owned; if (a.pack_event) (void)hipStreamWaitEvent(a.stream, a.pack_event, 0); }
+    const int64_t total = (ne - nb) * Rec<M>::N;
+    if (total > 0) {
+      int64_t grid = (total + 255) / 256;
+      if (grid > 4096) grid = 4096;
+      hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux,
+                         a.packed);
+    }
+    if (a.pack_part == 1 && a.pack_event) (void)hipEventRecord(a.pack_event, a.stream);
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);

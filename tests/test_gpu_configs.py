@@ -1,0 +1,210 @@
+"""BASELINE.json configs[2..4] at their stated sizes on the GPU (cfg2 K(55) is in test_gpu_parity.py).
+
+  cfg3  RIPF133, 5M TET4            K(94)  = 4,983,504 tets   against the oracle on the whole mesh, both parameter sets
+  cfg5  coupled_hcc + solid, 2M HEX8 H(126) = 2,000,376 hexes  HCC: oracle on the whole mesh; solid: oracle on a slab of
+                                                              elements (rows of the nodes interior to the slab) + the
+                                                              rigid-translation null space of the whole Jacobian
+  cfg4  PIHNA 10M TET4, 8-way split K(119) / 8               two of the eight local partitions (owned + ghost layer)
+                                                              assembled on the one GPU: exact mass-matrix limit and
+                                                              agreement of the two independent scatter strategies
+
+The oracle runs on the host cores of the box (oracle_assemble_mt: rows split over threads, bitwise equal to its
+serial loop -- tests/test_oracle_mt.py).  Tolerance as everywhere: 1e-10 relative (north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+from rdcfes_amd import (AssemblyContext, SolidMaterial, SolidParams, hcc_params_from_dict, partition,
+                        pihna_params_from_dict, ripf_params_from_dict, synth)
+from rdcfes_amd.context import (FIELD_AUX_NODAL, FIELD_ELEM_FIBRE, FIELD_OLD_SOLUTION, FIELD_UNDEFORMED_XYZ,
+                                SCATTER_COLOURED, SCATTER_ROWGATHER)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+# ---- cfg3 -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def k94(oracle):
+    conn, xyz = synth.kuhn_tet_mesh(94, order="lex")
+    assert conn.shape[0] == 4983504 and xyz.shape[0] == 857375
+    pattern = oracle.build_pattern(4, conn, xyz.shape[0], xyz.shape[0], 3)[:2]
+    return conn, xyz, pattern
+
+
+@pytest.mark.parametrize("pvariant", ["shipped", "full"])
+def test_cfg3_ripf_k94_against_oracle(oracle, k94, pvariant):
+    conn, xyz, pattern = k94
+    u, aux = synth.ripf_fields(xyz)
+    p = ripf_params_from_dict(synth.ripf_param_dict(pvariant))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_RIPF, 4, conn, xyz, 3, p, u_old=u, aux=aux, pattern=pattern, threads=THREADS)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(4, conn, xyz, 3)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.field_upload(FIELD_AUX_NODAL, aux)
+        ctx.assemble_ripf(p)
+        val, rhs = ctx.csr_download()
+        rp, col = ctx.csr_pattern()
+    assert np.array_equal(rp, pattern[0]) and np.array_equal(col, pattern[1])
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
+# ---- cfg5 -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def h126(oracle):
+    conn, xyz = synth.hex_mesh(126, jitter=0.15, order="lex")
+    assert conn.shape[0] == 2000376 and xyz.shape[0] == 2048383
+    pattern = oracle.build_pattern(8, conn, xyz.shape[0], xyz.shape[0], 3)[:2]  # HCC and the solid system: 3 unknowns each
+    return conn, xyz, pattern
+
+
+def test_cfg5_hcc_h126_against_oracle(oracle, h126):
+    """the reaction-diffusion half of cfg5 on the CURRENT (deformed) coordinates, src/coupled_hcc.C:98-114"""
+    conn, Xu, pattern = h126
+    x = Xu + synth.solid_displacement(Xu, amp=0.02 / 126 * 8)   # a deformation of a fraction of the cell size
+    u = synth.hcc_fields(Xu)
+    p = hcc_params_from_dict(synth.hcc_param_dict("full"))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_HCC, 8, conn, x, 3, p, u_old=u, pattern=pattern, threads=THREADS)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(8, conn, Xu, 3)
+        ctx.mesh_update_coords(x)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_hcc(p)
+        val, rhs = ctx.csr_download()
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
+def test_cfg5_solid_h126(oracle, h126):
+    """the solid half of cfg5: residual + Jacobian of every element of H(126) in one call."""
+    conn, Xu, pattern = h126
+    rp, col = pattern
+    n, ne = 126, conn.shape[0]
+    x = Xu + synth.solid_displacement(Xu, amp=0.02 / 126 * 8)
+    cen = Xu[conn].mean(axis=1)
+    em = (np.linalg.norm(cen - 0.5, axis=1) < 0.3).astype(np.int32)       # growing inclusion, run/Coupled/HCC/input.dat:44-53
+    mats = [SolidMaterial(2.0e3, 0.4, 0.0, (0.0, 0.0, 0.0)), SolidMaterial(2.0e3, 0.4, 25.0, (0.3, 0.3, 0.3))]
+    fibre = np.random.default_rng(11).standard_normal((ne, 3))
+    sp = SolidParams(0.4, 1.0e8, 0, 0)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(8, conn, x, 3)
+        ctx.field_upload(FIELD_UNDEFORMED_XYZ, Xu)
+        ctx.field_upload(FIELD_ELEM_FIBRE, fibre)
+        ctx.solid_set_materials(em, mats)
+        ctx.solid_assemble(sp, True)          # no boundary sides: the pure element part (a4/a5)
+        val, rhs = ctx.csr_download()
+    # (1) oracle on a slab of three element layers through the inclusion; rows of the nodes whose eight elements all
+    #     lie inside the slab are complete there
+    k0 = n // 2 - 1
+    e0, e1 = k0 * n * n, (k0 + 3) * n * n
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_SOLID, 8, conn, x, 3, sp, xyz_undeformed=Xu, elem_fibre=fibre,
+                                       elem_material=em, materials=mats, request_jacobian=True, pattern=pattern,
+                                       e_begin=e0, e_end=e1, threads=THREADS)
+    cnt_all = np.bincount(conn.ravel(), minlength=Xu.shape[0])
+    cnt_slab = np.bincount(conn[e0:e1].ravel(), minlength=Xu.shape[0])
+    inner = np.flatnonzero((cnt_slab == cnt_all) & (cnt_slab > 0))
+    assert inner.size == 2 * (n + 1) ** 2
+    rows = (inner[:, None] * 3 + np.arange(3)[None, :]).ravel()
+    assert rel(rhs[rows], rhs0[rows]) < TOL
+    lo, hi = rp[rows[0]], rp[rows[-1] + 1]      # the inner nodes are one contiguous run in the lexicographic numbering
+    assert np.array_equal(rows, np.arange(rows[0], rows[-1] + 1))
+    assert rel(val[lo:hi], val0[lo:hi]) < TOL
+    assert np.abs(em[e0:e1]).max() == 1 and np.abs(val0[lo:hi]).max() > 0
+    # (2) whole mesh: a rigid translation is in the null space of the element Jacobian (no penalty sides): for every row
+    #     the entries of each displacement component sum to zero
+    v3 = val.reshape(-1, 3)
+    row_sums = np.add.reduceat(v3, rp[:-1] // 3, axis=0)
+    row_abs = np.add.reduceat(np.abs(v3), rp[:-1] // 3, axis=0).sum(axis=1)
+    assert np.isfinite(val).all() and row_abs.min() > 0
+    assert (np.abs(row_sums).max(axis=1) / row_abs).max() < 1e-11
+    # (3) and the residual of the interior nodes is the divergence of a stress field: the sum over ALL nodes of every
+    #     component vanishes (sum_i grad phi_i = 0)
+    assert np.abs(rhs.reshape(-1, 3).sum(axis=0)).max() < 1e-9 * np.abs(rhs).sum()
+
+
+# ---- cfg4 -------------------------------------------------------------------------------------------------------
+def _tet_volumes(xyz, conn):
+    X = xyz[conn]
+    return np.abs(np.einsum("ei,ei->e", X[:, 1] - X[:, 0], np.cross(X[:, 2] - X[:, 0], X[:, 3] - X[:, 0]))) / 6.0
+
+
+def test_cfg4_eightway_partition_of_k119():
+    """Two of the eight RCB partitions of the metric's mesh, each with its ghost layer, as the 8-GPU run assembles them."""
+    conn, xyz = synth.kuhn_tet_mesh(119, order="lex")
+    assert conn.shape[0] == 10110954
+    u = synth.pihna_fields(xyz)
+    part = partition.partition_rcb(xyz[conn].mean(axis=1), 8)
+    sizes = np.bincount(part, minlength=8)
+    assert sizes.max() - sizes.min() <= 1
+    owner = partition.node_owners(conn, part, xyz.shape[0], 8)
+    p0 = pihna_params_from_dict({"time_step": 0.1, "cells_max_capacity": 2.39e5, "cells_max_capacity/exponent": 3.0,
+                                 "cytokines_max_capacity": 1e-8})
+    p1 = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    for rank in (0, 5):
+        lp = partition.build_local(conn, xyz, part, rank, 8, owner=owner)
+        assert lp.n_elem_owned == sizes[rank] and lp.conn.shape[0] > lp.n_elem_owned      # ghost layer present
+        assert 0 < lp.n_interior < lp.n_owned
+        lu = u[lp.node_global]
+        with AssemblyContext(0) as ctx:
+            ctx.mesh_upload(4, lp.conn, lp.xyz, 5, n_owned=lp.n_owned)
+            ctx.field_upload(FIELD_OLD_SOLUTION, lu)
+            # (1) all rates zero: K = block-diagonal mass matrix, F = M u_old -- exact closed form on TET4
+            #     (M_ij = V/20 (1 + delta_ij); the 5-point rule integrates quadratics exactly)
+            ctx.assemble_pihna(p0)
+            val, rhs = ctx.csr_download()
+            rp, col = ctx.csr_pattern()
+            vol = _tet_volumes(lp.xyz, lp.conn)
+            lc = lp.conn.astype(np.int64)
+            nn = lp.xyz.shape[0]
+            # expected rhs of the owned nodes
+            exp_rhs = np.zeros((nn, 5))
+            usum = lu[lc].sum(axis=1)
+            for i in range(4):
+                np.add.at(exp_rhs, lc[:, i], (vol / 20.0)[:, None] * (usum + lu[lc[:, i]]))
+            exp_rhs = exp_rhs[:lp.n_owned].ravel()
+            assert np.abs(rhs - exp_rhs).max() <= 1e-12 * np.abs(exp_rhs).max()
+            # expected mass entries on the node pattern: rows a = 0 hold (J, b) in ascending order
+            r0 = np.arange(lp.n_owned) * 5
+            starts, lens = rp[r0], (rp[r0 + 1] - rp[r0]) // 5
+            node_of_block = np.repeat(np.arange(lp.n_owned), lens)
+            first = np.repeat(starts, lens) + 5 * (np.arange(lens.sum()) - np.repeat(np.cumsum(lens) - lens, lens))
+            key = node_of_block * nn + col[first] // 5
+            assert np.all(np.diff(key) > 0)
+            M = np.zeros(key.size)
+            for i in range(4):
+                own = lc[:, i] < lp.n_owned
+                for j in range(4):
+                    pos = np.searchsorted(key, lc[own, i] * nn + lc[own, j])
+                    np.add.at(M, pos, vol[own] / 20.0 * (2.0 if i == j else 1.0))
+            rowlen = np.repeat(lens * 5, lens)
+            for a in range(5):
+                for b in range(5):
+                    got = val[first + a * rowlen + b]
+                    if a == b:
+                        assert np.abs(got - M).max() <= 1e-12 * M.max()
+                    else:
+                        assert np.abs(got).max() == 0.0
+            del val, rhs, M, key, first
+            # (2) shipped parameters: row gather and coloured scatter agree on the partition
+            ctx.set_scatter(SCATTER_ROWGATHER)
+            ctx.assemble_pihna(p1)
+            v_rg, r_rg = ctx.csr_download()
+            ctx.set_scatter(SCATTER_COLOURED)
+            ctx.assemble_pihna(p1)
+            v_c, r_c = ctx.csr_download()
+            assert rel(v_c, v_rg) < 1e-12 and rel(r_c, r_rg) < 1e-12
+            # (3) the two-part assembly around the halo exchange gives the same rows
+            ctx.set_scatter(SCATTER_ROWGATHER)
+            ctx.set_option("interior_nodes", int(lp.n_interior))
+            ctx.set_option("part", 1)
+            ctx.assemble_pihna(p1)
+            ctx.set_option("part", 2)
+            ctx.assemble_pihna(p1)
+            ctx.set_option("part", 0)
+            v_2, r_2 = ctx.csr_download()
+            assert rel(v_2, v_rg) < 1e-13 and rel(r_2, r_rg) < 1e-13

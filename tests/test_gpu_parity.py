@@ -453,3 +453,50 @@ def test_pihna_shipped_pattern_branches(oracle, moments):
     ok, okr = ~np.isnan(val0), ~np.isnan(rhs0)
     assert rel(val[ok], val0[ok]) < TOL and rel(rhs[okr], rhs0[okr]) < TOL
     np.testing.assert_allclose(val[ok], val0[ok], rtol=1e-9, atol=1e-12 * np.abs(val0[ok]).max())
+
+
+def test_two_part_assembly_on_two_streams(oracle):
+    """The stream contract of rdc_set_option("part") (include/rdc_assembly.h): part 1 on one stream while the ghost rows
+    of the bound solution are rewritten on another, part 2 behind that rewrite on the second stream.  Part 1 must not
+    read (or publish) a ghost value, part 2 must see the new ones whatever the order in which the GPU runs the two."""
+    import torch
+    from rdcfes_amd import partition
+    conn, xyz = synth.kuhn_tet_mesh(20, order="lex")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    part = partition.partition_rcb(xyz[conn].mean(axis=1), 2)
+    lp = partition.build_local(conn, xyz, part, 0, 2)
+    assert 0 < lp.n_interior < lp.n_owned < lp.node_global.size
+    dev = torch.device("cuda", 0)
+    main_s, side_s = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+    ghost_idx = torch.arange(lp.n_owned, lp.node_global.size, device=dev)
+    lu = u[lp.node_global]
+    with AssemblyContext(0) as ctx:
+        ctx.set_stream(main_s.cuda_stream)
+        ctx.mesh_upload(4, lp.conn, lp.xyz, 5, n_owned=lp.n_owned)
+        u_t = torch.from_numpy(lu.copy()).to(dev)
+        ctx.field_bind_device(FIELD_OLD_SOLUTION, u_t.data_ptr(), u_t.numel())
+        ctx.set_option("interior_nodes", int(lp.n_interior))
+        for step in range(4):
+            scale = 1.0 + 0.25 * step                       # this step's ghost values
+            new_ghosts = torch.from_numpy(lu[lp.n_owned:] * scale).to(dev)
+            torch.cuda.synchronize()
+            u_t[lp.n_owned:] = float("nan")                 # what part 1 would pick up if it looked at a ghost
+            torch.cuda.synchronize()
+            side_s.wait_stream(main_s)
+            ctx.set_option("part", 1)
+            ctx.assemble_pihna(p)                           # main stream
+            with torch.cuda.stream(side_s):
+                u_t.index_copy_(0, ghost_idx, new_ghosts)   # stands in for the halo exchange
+            ctx.set_stream(side_s.cuda_stream)
+            ctx.set_option("part", 2)
+            ctx.assemble_pihna(p)                           # side stream, behind the "exchange"
+            ctx.set_stream(main_s.cuda_stream)
+            main_s.wait_stream(side_s)
+            ctx.set_option("part", 0)
+            val, rhs = ctx.csr_download()
+            exp_u = lu.copy()
+            exp_u[lp.n_owned:] *= scale
+            _, _, val0, rhs0 = oracle.assemble(0, 4, lp.conn, lp.xyz, 5, p, u_old=exp_u, n_owned=lp.n_owned)
+            assert np.isfinite(val).all() and np.isfinite(rhs).all()
+            assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
