@@ -25,6 +25,8 @@
 #include <memory>
 #include <stdexcept>
 #include <ostream>
+#include <set>
+#include <sstream>
 #include <string>
 #include <variant>
 #include <vector>
@@ -40,6 +42,27 @@ using dof_id_type = uint32_t;
 
 inline void check(rdc_ctx* c, int rc, const char* what) {
   if (rc != RDC_OK) throw std::runtime_error(std::string(what) + ": " + rdc_last_error(c));
+}
+
+// libMesh::Point as far as the parameters need it ("BC/<id>/displacement", src/solid.C:246-256)
+struct Point {
+  double c[3] = {0.0, 0.0, 0.0};
+  Point() = default;
+  Point(double x, double y, double z) : c{x, y, z} {}
+  double& operator()(int d) { return c[d]; }
+  double operator()(int d) const { return c[d]; }
+};
+
+// src/utils.h:268-288: the integers of a blank-separated string ("BCs", "materials", "loading_time_points")
+inline std::set<int> export_integers(const std::string& s) {
+  std::set<int> numbers;
+  std::stringstream ss(s);
+  std::string tmp;
+  while (ss >> tmp) {
+    int n;
+    if (std::stringstream(tmp) >> n) numbers.insert(n);
+  }
+  return numbers;
 }
 
 // ---- libMesh::Parameters (string-keyed, typed) ------------------------------------------------
@@ -61,7 +84,7 @@ class Parameters {
     return it != map_.end() && std::holds_alternative<T>(it->second);
   }
  private:
-  std::map<std::string, std::variant<Real, int, bool, std::string>> map_;
+  std::map<std::string, std::variant<Real, int, bool, std::string, Point>> map_;
 };
 
 // ---- mesh: FIRST-order TET4 / HEX8, libMesh node order -----------------------------------------
@@ -79,10 +102,22 @@ class Mesh {
   const std::vector<uint32_t>& connectivity() const { return conn_; }
   std::vector<double>& coordinates() { return xyz_; }              // moving mesh (SolidSystem::update)
   const std::vector<double>& coordinates() const { return xyz_; }
+  // elem->subdomain_id() (first Gmsh tag of the volume elements); all 0 unless set
+  void set_subdomain_ids(std::vector<int32_t> ids) {
+    if ((int64_t)ids.size() != n_elem()) throw std::runtime_error("Mesh: one subdomain id per element");
+    subdomain_ = std::move(ids);
+  }
+  int32_t subdomain_id(int64_t e) const { return subdomain_.empty() ? 0 : subdomain_[(size_t)e]; }
+  // get_boundary_info(): (element, libMesh side number, boundary id) of the tagged boundary faces
+  struct BoundarySide { int64_t elem; int32_t side; int32_t id; };
+  void add_side(int64_t elem, int32_t side, int32_t id) { sides_.push_back({elem, side, id}); }
+  const std::vector<BoundarySide>& boundary_sides() const { return sides_; }
  private:
   int elem_type_;
   std::vector<uint32_t> conn_;
   std::vector<double> xyz_;
+  std::vector<int32_t> subdomain_;
+  std::vector<BoundarySide> sides_;
 };
 
 // ---- NumericVector / SparseMatrix (host copies; the GPU owns the assembled values) --------------
@@ -132,6 +167,10 @@ class System {
   const std::string& name() const { return name_; }
   unsigned int add_variable(const std::string& var) { vars_.push_back(var); return (unsigned)vars_.size() - 1; }
   unsigned int n_vars() const { return (unsigned)vars_.size(); }
+  unsigned int variable_number(const std::string& var) const {
+    for (size_t v = 0; v < vars_.size(); v++) if (vars_[v] == var) return (unsigned)v;
+    throw std::runtime_error("System::variable_number: no variable '" + var + "' in " + name_);
+  }
   EquationSystems& get_equation_systems() { return es_; }
   // dof = node * n_vars + var (libMesh variable-group numbering)
   NumericVector solution, current_local_solution;
@@ -141,30 +180,59 @@ class System {
     solution.init(n_nodes * n_vars());
     current_local_solution.init(n_nodes * n_vars());
   }
-  void update() { current_local_solution = solution; }  // serial: ghost update is the identity
+  virtual void update() { current_local_solution = solution; }  // serial: ghost update is the identity
+  virtual void init_data() {}                                   // called by EquationSystems::init() after the vectors exist
  protected:
   EquationSystems& es_;
   std::string name_;
   std::vector<std::string> vars_;
 };
 
-class TransientLinearImplicitSystem : public System {
+using ExplicitSystem = System;
+
+class TransientExplicitSystem : public System {   // "SolidSystem::auxiliary" (src/solid.C:34-37)
  public:
-  using AssembleFn = void (*)(EquationSystems&, const std::string&);
   using System::System;
-  NumericVector old_local_solution, older_local_solution, rhs_storage;
+  NumericVector old_local_solution, older_local_solution;
+  void init(int64_t n) override {
+    System::init(n);
+    old_local_solution.init(n * n_vars());
+    older_local_solution.init(n * n_vars());
+  }
+};
+
+// a system with a matrix and a right-hand side: EquationSystems::init() gives it an assembly context and the pattern
+class ImplicitSystem : public System {
+ public:
+  using System::System;
+  NumericVector rhs_storage;
   SparseMatrix matrix_storage;
   NumericVector* rhs = &rhs_storage;
   SparseMatrix* matrix = &matrix_storage;
+  void init(int64_t n_nodes) override {
+    System::init(n_nodes);
+    rhs_storage.init(n_nodes * n_vars());
+  }
+};
+
+// BiCGStab preconditioned with ILU(0) of the assembled matrix: the stand-in for "linear_solver->solve(matrix,
+// solution, rhs)" (the reference hands the system to PETSc KSP -- GMRES + ILU(0) by default --, which stays on the
+// host and is out of this project's scope).  Returns the iteration count.
+inline int bicgstab_ilu0(const SparseMatrix& A, const std::vector<double>& b, std::vector<double>& x, Real tol, int max_its);
+
+class TransientLinearImplicitSystem : public ImplicitSystem {
+ public:
+  using AssembleFn = void (*)(EquationSystems&, const std::string&);
+  using ImplicitSystem::ImplicitSystem;
+  NumericVector old_local_solution, older_local_solution;
   Real time = 0.0;
   void attach_assemble_function(AssembleFn f) { assemble_fn_ = f; }
   Number old_solution(dof_id_type dof) const { return old_local_solution((int64_t)dof); }
   SparseMatrix& get_system_matrix() { return matrix_storage; }
   void init(int64_t n_nodes) override {
-    System::init(n_nodes);
+    ImplicitSystem::init(n_nodes);
     old_local_solution.init(n_nodes * n_vars());
     older_local_solution.init(n_nodes * n_vars());
-    rhs_storage.init(n_nodes * n_vars());
   }
   // ImplicitSystem::assemble(): zero matrix and rhs, then System::user_assembly() -> the callback
   void assemble() {
@@ -206,7 +274,7 @@ class EquationSystems {
   void init() {
     for (auto& kv : systems_) {
       kv.second->init(kv.second->elemental ? mesh_.n_elem() : mesh_.n_nodes());
-      if (auto* t = dynamic_cast<TransientLinearImplicitSystem*>(kv.second.get())) {
+      if (auto* t = dynamic_cast<ImplicitSystem*>(kv.second.get())) {
         rdc_ctx* c = context(t->name(), (int)t->n_vars());
         int64_t n_rows = 0, nnz = 0;
         check(c, rdc_csr_dims(c, &n_rows, &nnz), "rdc_csr_dims");
@@ -216,7 +284,9 @@ class EquationSystems {
         check(c, rdc_csr_pattern_download(c, t->matrix_storage.row_ptr.data(), t->matrix_storage.col_idx.data()), "pattern");
       }
     }
+    for (auto& kv : systems_) kv.second->init_data();
   }
+  void reinit() {}   // es.reinit() (src/solid_system.C:391): nothing to redistribute on a fixed serial mesh
   // one assembly context (GPU-resident mesh + pattern) per implicit system
   rdc_ctx* context(const std::string& system, int nvar) {
     auto it = ctx_.find(system);
@@ -236,15 +306,46 @@ class EquationSystems {
   std::map<std::string, rdc_ctx*> ctx_;
 };
 
-// BiCGStab with Jacobi preconditioning: a stand-in for "linear_solver->solve(matrix, solution, rhs)".
-inline int TransientLinearImplicitSystem::solve(Real tol, int max_its) {
-  assemble();
-  const SparseMatrix& A = matrix_storage;
-  const std::vector<double>& b = rhs_storage.raw();
-  std::vector<double>& x = solution.raw();
+inline int bicgstab_ilu0(const SparseMatrix& A, const std::vector<double>& b, std::vector<double>& x, Real tol, int max_its) {
   const size_t n = b.size();
-  std::vector<double> dinv(n, 1.0), r(n), r0(n), p(n, 0.0), v(n, 0.0), s(n), t(n), y(n), z(n), tmp;
-  for (size_t i = 0; i < n; i++) { const double d = A((int64_t)i, (int64_t)i); if (d != 0.0) dinv[i] = 1.0 / d; }
+  // ILU(0) on the pattern of A (columns ascending within a row, diagonal present)
+  std::vector<double> lu = A.val;
+  std::vector<int64_t> diag(n, -1);
+  for (size_t i = 0; i < n; i++)
+    for (int64_t k = A.row_ptr[i]; k < A.row_ptr[i + 1]; k++) if ((size_t)A.col_idx[(size_t)k] == i) diag[i] = k;
+  for (size_t i = 0; i < n; i++) if (diag[i] < 0) throw std::runtime_error("bicgstab_ilu0: missing diagonal entry");
+  {
+    std::vector<int64_t> pos(n, -1);
+    for (size_t i = 0; i < n; i++) {
+      for (int64_t k = A.row_ptr[i]; k < A.row_ptr[i + 1]; k++) pos[(size_t)A.col_idx[(size_t)k]] = k;
+      for (int64_t k = A.row_ptr[i]; k < diag[i]; k++) {
+        const size_t j = (size_t)A.col_idx[(size_t)k];
+        const double piv = lu[(size_t)diag[j]];
+        if (piv == 0.0) throw std::runtime_error("bicgstab_ilu0: zero pivot");
+        const double l = lu[(size_t)k] / piv;
+        lu[(size_t)k] = l;
+        for (int64_t m = diag[j] + 1; m < A.row_ptr[j + 1]; m++) {
+          const int64_t q = pos[(size_t)A.col_idx[(size_t)m]];
+          if (q >= 0) lu[(size_t)q] -= l * lu[(size_t)m];
+        }
+      }
+      for (int64_t k = A.row_ptr[i]; k < A.row_ptr[i + 1]; k++) pos[(size_t)A.col_idx[(size_t)k]] = -1;
+    }
+  }
+  auto precond = [&](const std::vector<double>& r, std::vector<double>& z) {
+    z = r;
+    for (size_t i = 0; i < n; i++) {
+      double s = z[i];
+      for (int64_t k = A.row_ptr[i]; k < diag[i]; k++) s -= lu[(size_t)k] * z[(size_t)A.col_idx[(size_t)k]];
+      z[i] = s;
+    }
+    for (size_t i = n; i-- > 0;) {
+      double s = z[i];
+      for (int64_t k = diag[i] + 1; k < A.row_ptr[i + 1]; k++) s -= lu[(size_t)k] * z[(size_t)A.col_idx[(size_t)k]];
+      z[i] = s / lu[(size_t)diag[i]];
+    }
+  };
+  std::vector<double> r(n), r0(n), p(n, 0.0), v(n, 0.0), s(n), t(n), y(n), z(n), tmp;
   A.vector_mult(tmp, x);
   double bn = 0.0;
   for (size_t i = 0; i < n; i++) { r[i] = b[i] - tmp[i]; r0[i] = r[i]; bn += b[i] * b[i]; }
@@ -255,20 +356,36 @@ inline int TransientLinearImplicitSystem::solve(Real tol, int max_its) {
     double rn = 0, rho1 = 0;
     for (size_t i = 0; i < n; i++) { rn += r[i] * r[i]; rho1 += r0[i] * r[i]; }
     if (std::sqrt(rn) <= tol * bn) break;
+    if (rho1 == 0.0) {  // breakdown: restart with the current residual as the shadow vector
+      r0 = r;
+      rho1 = rn;
+      std::fill(p.begin(), p.end(), 0.0);
+      std::fill(v.begin(), v.end(), 0.0);
+      rho = alpha = omega = 1;
+    }
     const double beta = (rho1 / rho) * (alpha / omega);
     rho = rho1;
-    for (size_t i = 0; i < n; i++) { p[i] = r[i] + beta * (p[i] - omega * v[i]); y[i] = dinv[i] * p[i]; }
+    for (size_t i = 0; i < n; i++) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+    precond(p, y);
     A.vector_mult(v, y);
     double r0v = 0;
     for (size_t i = 0; i < n; i++) r0v += r0[i] * v[i];
     alpha = rho / r0v;
-    for (size_t i = 0; i < n; i++) { s[i] = r[i] - alpha * v[i]; z[i] = dinv[i] * s[i]; }
+    for (size_t i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
+    precond(s, z);
     A.vector_mult(t, z);
     double ts = 0, tt = 0;
     for (size_t i = 0; i < n; i++) { ts += t[i] * s[i]; tt += t[i] * t[i]; }
     omega = tt > 0 ? ts / tt : 0.0;
     for (size_t i = 0; i < n; i++) { x[i] += alpha * y[i] + omega * z[i]; r[i] = s[i] - omega * t[i]; }
+    if (omega == 0.0) break;
   }
+  return it;
+}
+
+inline int TransientLinearImplicitSystem::solve(Real tol, int max_its) {
+  assemble();
+  const int it = bicgstab_ilu0(matrix_storage, rhs_storage.raw(), solution.raw(), tol, max_its);
   update();
   return it;
 }
@@ -473,6 +590,225 @@ inline void save_solution_ripf(std::ostream& csv, EquationSystems& es) {
   check(c, rdc_field_upload(c, RDC_FIELD_OLD_SOLUTION, system.solution.raw().data(), system.solution.size()), "solution");
   check(c, rdc_ripf_volume_integrals(c, &r, -1, v), "rdc_ripf_volume_integrals");
   csv << system.time << ',' << v[0] << ',' << v[1] << std::endl;
+}
+
+
+// ---- SolidSystem: the FEMSystem subclass of src/solid_system.h:30-84 -----------------------------------------
+// The reference implements the per-element virtuals element_time_derivative / side_time_derivative
+// (src/solid_system.C:146-371) and lets libMesh's FEMSystem::assembly() loop over the elements and sides and add
+// their results into the global Jacobian and residual, once per Newton iteration.  The GPU drop-in replaces that
+// WHOLE loop: assembly(get_residual, get_jacobian) marshals what the virtuals read -- the current node positions
+// (the unknowns; the mesh IS the solution, :103-123), the undeformed positions of "SolidSystem::auxiliary"
+// (:221-229), the reference fibre of "SolidSystem::fibre" (:204-216), the material of each subdomain (:183-190), the
+// boundary sides named by "BCs" with their prescribed displacement (:294-306), "pseudo_time",
+// "BCs/displacement_penalty", "solver/assembly_use_symmetry" -- and makes ONE call, rdc_solid_assemble.
+// solve() is a plain Newton iteration with the options init_data() reads (:84-100), standing in for libMesh's
+// NewtonSolver + PETSc; everything else keeps the reference's names: init_data, save_initial_mesh, update,
+// run_solver, post_process, update_data, var[], undefo_var[], deltat.
+class SolidSystem : public ImplicitSystem {
+ public:
+  using ImplicitSystem::ImplicitSystem;
+  unsigned int var[3] = {0, 1, 2}, undefo_var[3] = {0, 1, 2};
+  Real deltat = 0.0;
+  // DiffSolver options (src/solid_system.C:84-100)
+  bool quiet = true, require_residual_reduction = false;
+  int max_nonlinear_iterations = 10, max_linear_iterations = 50000;
+  Real relative_step_tolerance = 1e-3, relative_residual_tolerance = 1e-8, absolute_residual_tolerance = 1e-8,
+       initial_linear_tolerance = 1e-3;
+  // what the last solve() did (the reference prints this through NewtonSolver's verbose mode)
+  struct NewtonLog { int nonlinear_iterations = 0, linear_iterations = 0, assemblies = 0; Real first_residual = 0, last_residual = 0; bool converged = false; };
+  NewtonLog last;
+
+  std::string system_type() const { return "SolidSystem"; }
+
+  void init_data() override;                                   // src/solid_system.C:49-101
+  void save_initial_mesh();                                    // :26-47
+  void update() override;                                      // :103-123
+  void assembly(bool get_residual, bool get_jacobian);         // FEMSystem::assembly -> the :146-371 virtuals
+  void solve();                                                // FEMSystem::solve() -> SteadySolver -> NewtonSolver
+  void run_solver();                                           // :373-392
+  void post_process();                                         // :394-538
+  void update_data();                                          // :540-557
+  void rebind() { bound_ = false; }                            // materials / BC sides are re-read from es.parameters
+
+ private:
+  bool bound_ = false;
+  void bind(rdc_ctx* c);
+};
+
+inline void SolidSystem::init_data() {
+  Parameters& P = es_.parameters;
+  var[0] = variable_number("x"); var[1] = variable_number("y"); var[2] = variable_number("z");
+  System& aux = es_.get_system<System>("SolidSystem::auxiliary");
+  undefo_var[0] = aux.variable_number("undeformed_x");
+  undefo_var[1] = aux.variable_number("undeformed_y");
+  undefo_var[2] = aux.variable_number("undeformed_z");
+  deltat = P.get<Real>("loading_step");
+  if (!P.have_parameter<Real>("BCs/displacement_penalty")) P.set<Real>("BCs/displacement_penalty") = 1.0e+5;
+  // mesh_position_get(): the unknowns start as the node positions
+  solution.raw() = es_.get_mesh().coordinates();
+  current_local_solution = solution;
+  quiet = P.get<bool>("solver/quiet");
+  max_nonlinear_iterations = P.get<int>("solver/nonlinear/max_nonlinear_iterations");
+  relative_step_tolerance = P.get<Real>("solver/nonlinear/relative_step_tolerance");
+  relative_residual_tolerance = P.get<Real>("solver/nonlinear/relative_residual_tolerance");
+  absolute_residual_tolerance = P.get<Real>("solver/nonlinear/absolute_residual_tolerance");
+  if (!P.have_parameter<bool>("solver/assembly_use_symmetry")) P.set<bool>("solver/assembly_use_symmetry") = false;
+  require_residual_reduction = P.get<bool>("solver/nonlinear/require_reduction");
+  max_linear_iterations = P.get<int>("solver/linear/max_linear_iterations");
+  initial_linear_tolerance = P.get<Real>("solver/linear/initial_linear_tolerance");
+}
+
+inline void SolidSystem::save_initial_mesh() {
+  System& aux = es_.get_system<System>("SolidSystem::auxiliary");
+  aux.current_local_solution = current_local_solution;  // same (node, component) numbering in both systems
+  aux.solution = aux.current_local_solution;
+}
+
+inline void SolidSystem::update() {
+  System::update();
+  es_.get_mesh().coordinates() = current_local_solution.raw();   // mesh_position_set()
+  System& disp = es_.get_system<System>("SolidSystem::displacement");
+  System& aux = es_.get_system<System>("SolidSystem::auxiliary");
+  disp.current_local_solution = current_local_solution;
+  for (size_t i = 0; i < disp.current_local_solution.raw().size(); i++)
+    disp.current_local_solution.raw()[i] -= aux.current_local_solution.raw()[i];
+  disp.solution = disp.current_local_solution;
+}
+
+// one-time marshalling of what does not change between Newton iterations
+inline void SolidSystem::bind(rdc_ctx* c) {
+  const Parameters& P = es_.parameters;
+  const Mesh& mesh = es_.get_mesh();
+  // materials: one table entry per subdomain id present in the mesh (string-keyed lookups per element upstream)
+  std::map<int32_t, int32_t> index;
+  std::vector<rdc_solid_material> table;
+  std::vector<int32_t> elem_material((size_t)mesh.n_elem());
+  for (int64_t e = 0; e < mesh.n_elem(); e++) {
+    const int32_t id = mesh.subdomain_id(e);
+    auto it = index.find(id);
+    if (it == index.end()) {
+      const std::string k = "material/" + std::to_string(id) + "/Hyperelastic/";
+      rdc_solid_material m;
+      m.Young = P.get<Real>(k + "Young"); m.Poisson = P.get<Real>(k + "Poisson"); m.FibreStiffness = P.get<Real>(k + "FibreStiffness");
+      for (int d = 0; d < 3; d++) m.rate[d] = P.get<Real>(k + "VolumetricStretchRatio/rate_" + std::to_string(d));
+      it = index.emplace(id, (int32_t)table.size()).first;
+      table.push_back(m);
+    }
+    elem_material[(size_t)e] = it->second;
+  }
+  check(c, rdc_solid_set_materials(c, elem_material.data(), (int32_t)table.size(), table.data()), "rdc_solid_set_materials");
+  // sides: every boundary side whose id is in "BCs", with "BC/<id>/displacement" (NaN component = unconstrained)
+  const std::set<int> bcs = export_integers(P.get<std::string>("BCs"));
+  std::vector<int64_t> se;
+  std::vector<int32_t> si;
+  std::vector<double> sd;
+  for (int bc : bcs) {   // ascending id, then mesh order: the order FEMSystem::assembly meets them does not matter for a sum
+    const Point& u = P.get<Point>("BC/" + std::to_string(bc) + "/displacement");
+    for (const Mesh::BoundarySide& s : mesh.boundary_sides()) {
+      if (s.id != bc) continue;
+      se.push_back(s.elem); si.push_back(s.side);
+      for (int d = 0; d < 3; d++) sd.push_back(u(d));
+    }
+  }
+  check(c, rdc_solid_set_sides(c, (int64_t)se.size(), se.data(), si.data(), sd.data()), "rdc_solid_set_sides");
+  bound_ = true;
+}
+
+inline void SolidSystem::assembly(bool get_residual, bool get_jacobian) {
+  (void)get_residual;   // the residual always comes with the call, as in element_time_derivative
+  const Parameters& P = es_.parameters;
+  rdc_ctx* c = es_.context(name_, 3);
+  if (!bound_) bind(c);
+  System& aux = es_.get_system<System>("SolidSystem::auxiliary");
+  System& fibre = es_.get_system<System>("SolidSystem::fibre");
+  // FEMContext::pre_fe_reinit moves the element's nodes to the current iterate: current coordinates = unknowns
+  check(c, rdc_mesh_update_coords(c, current_local_solution.raw().data()), "rdc_mesh_update_coords");
+  check(c, rdc_field_upload(c, RDC_FIELD_UNDEFORMED_XYZ, aux.current_local_solution.raw().data(), aux.current_local_solution.size()), "undeformed coordinates");
+  const int64_t ne = es_.get_mesh().n_elem();
+  const unsigned int nf = fibre.n_vars();   // 6: reference x,y,z then current x,y,z (src/solid.C:44-50)
+  std::vector<double> eta((size_t)ne * 3);
+  for (int64_t e = 0; e < ne; e++)
+    for (int d = 0; d < 3; d++) eta[(size_t)e * 3 + d] = fibre.current_local_solution(e * nf + d);
+  check(c, rdc_field_upload(c, RDC_FIELD_ELEM_FIBRE, eta.data(), (int64_t)eta.size()), "fibre field");
+  rdc_solid_params p{};
+  p.pseudo_time = P.get<Real>("pseudo_time");
+  p.displacement_penalty = P.get<Real>("BCs/displacement_penalty");
+  p.use_symmetry = P.get<bool>("solver/assembly_use_symmetry") ? 1 : 0;
+  check(c, rdc_solid_assemble(c, &p, get_jacobian ? 1 : 0), "rdc_solid_assemble");
+  check(c, rdc_csr_download(c, get_jacobian ? matrix_storage.val.data() : nullptr, rhs_storage.raw().data()), "rdc_csr_download");
+  last.assemblies++;
+}
+
+inline void SolidSystem::solve() {
+  last = NewtonLog();
+  std::vector<double> delta(solution.raw().size()), minus_r(delta.size());
+  for (int it = 0;; it++) {
+    assembly(true, true);
+    const Real rn = rhs_storage.l2_norm();
+    if (it == 0) last.first_residual = rn;
+    last.last_residual = rn;
+    if (rn <= absolute_residual_tolerance || rn <= relative_residual_tolerance * last.first_residual) { last.converged = true; break; }
+    if (it >= max_nonlinear_iterations) break;
+    for (size_t i = 0; i < delta.size(); i++) { minus_r[i] = -rhs_storage.raw()[i]; delta[i] = 0.0; }
+    last.linear_iterations += bicgstab_ilu0(matrix_storage, minus_r, delta, initial_linear_tolerance, max_linear_iterations);
+    Real step = 1.0;
+    const std::vector<double> u0 = solution.raw();
+    for (;;) {   // full Newton step; halved while the residual does not go down if "require_reduction" is set
+      for (size_t i = 0; i < delta.size(); i++) solution.raw()[i] = u0[i] + step * delta[i];
+      update();
+      if (!require_residual_reduction || step < 1e-3) break;
+      assembly(true, false);
+      if (rhs_storage.l2_norm() < rn) break;
+      step *= 0.5;
+    }
+    last.nonlinear_iterations = it + 1;
+    long double dn = 0, un = 0;
+    for (size_t i = 0; i < delta.size(); i++) { dn += (long double)delta[i] * delta[i] * step * step; un += (long double)solution.raw()[i] * solution.raw()[i]; }
+    if (std::sqrt((double)dn) <= relative_step_tolerance * std::sqrt((double)un)) {
+      assembly(true, false);
+      last.last_residual = rhs_storage.l2_norm();
+      last.converged = true;
+      break;
+    }
+  }
+}
+
+inline void SolidSystem::run_solver() {
+  System& aux = es_.get_system<System>("SolidSystem::auxiliary");
+  solve();
+  aux.solution = aux.current_local_solution;
+  es_.reinit();
+}
+
+inline void SolidSystem::post_process() {
+  const Parameters& P = es_.parameters;
+  rdc_ctx* c = es_.context(name_, 3);
+  if (!bound_) bind(c);
+  System& aux = es_.get_system<System>("SolidSystem::auxiliary");
+  System& fibre = es_.get_system<System>("SolidSystem::fibre");
+  System& press = es_.get_system<System>("SolidSystem::pressure");
+  System& vm = es_.get_system<System>("SolidSystem::von_mises");
+  const int64_t ne = es_.get_mesh().n_elem();
+  const unsigned int nf = fibre.n_vars();
+  check(c, rdc_mesh_update_coords(c, current_local_solution.raw().data()), "rdc_mesh_update_coords");
+  check(c, rdc_field_upload(c, RDC_FIELD_UNDEFORMED_XYZ, aux.current_local_solution.raw().data(), aux.current_local_solution.size()), "undeformed coordinates");
+  std::vector<double> eta((size_t)ne * 3), cur((size_t)ne * 3);
+  for (int64_t e = 0; e < ne; e++)
+    for (int d = 0; d < 3; d++) eta[(size_t)e * 3 + d] = fibre.current_local_solution(e * nf + d);
+  check(c, rdc_field_upload(c, RDC_FIELD_ELEM_FIBRE, eta.data(), (int64_t)eta.size()), "fibre field");
+  rdc_solid_params p{};
+  p.pseudo_time = P.get<Real>("pseudo_time");
+  p.displacement_penalty = P.get<Real>("BCs/displacement_penalty");
+  check(c, rdc_solid_post_process(c, &p, press.solution.raw().data(), vm.solution.raw().data(), cur.data()), "rdc_solid_post_process");
+  for (int64_t e = 0; e < ne; e++)
+    for (int d = 0; d < 3; d++) fibre.solution.set(e * nf + 3 + d, cur[(size_t)e * 3 + d]);   // fibre_current_* (:526-527)
+}
+
+inline void SolidSystem::update_data() {
+  auto& aux = es_.get_system<TransientExplicitSystem>("SolidSystem::auxiliary");
+  aux.older_local_solution = aux.old_local_solution;
+  aux.old_local_solution = aux.current_local_solution;
 }
 
 }  // namespace host
