@@ -176,6 +176,8 @@ typedef struct rdc_solid_params {
 
 /* ---- context ---- */
 int rdc_abi_version(void);
+/* GPUs visible to this process (one MPI rank drives one of them: device_ordinal = node-local rank % count) */
+int rdc_device_count(int* n_devices);
 int rdc_ctx_create(int device_ordinal, rdc_ctx** out);
 int rdc_ctx_destroy(rdc_ctx* ctx);
 /* message for the last failing call on ctx (ctx may be NULL: last rdc_ctx_create failure) */

@@ -11,16 +11,34 @@
 //   1. add this file to src/ (Makefile:7 globs src/*.C), link with -lrdc_assembly;
 //   2. in src/pihna.C replace   model.attach_assemble_function(assemble_pihna);          (:35)
 //      by                       model.attach_assemble_function(rdc_gpu::assemble_pihna);
-//      (same for src/ripf.C:27 and src/coupled_hcc.C:37).  Nothing else changes: libMesh still zeroes
-//      matrix/rhs, calls the callback once per time step on every rank, closes matrix/rhs and hands
-//      them to PETSc KSP.
+//      (same for src/ripf.C:27, src/coupled_hcc.C:37, src/adpm.C, src/proteas.C).  Nothing else changes:
+//      libMesh still zeroes matrix/rhs, calls the callback once per time step on every rank, closes
+//      matrix/rhs and hands them to PETSc KSP.
+//   3. solid mechanics: replace   es.add_system<SolidSystem>("SolidSystem")           (src/solid.C:27, src/coupled_hcc.C:40)
+//      by                         es.add_system<rdc_gpu::SolidSystemGPU>("SolidSystem")
+//      -- a subclass of the reference's SolidSystem that overrides FEMSystem::assembly(), so that one
+//      rdc_solid_assemble call replaces the per-element element_time_derivative / side_time_derivative
+//      virtuals (src/solid_system.C:146-371) of every Newton iteration.
+//   4. MORE THAN ONE MPI RANK: the GPU context of a rank holds its local elements PLUS the neighbouring elements that
+//      touch one of its nodes, and reads the old solution (and the TD / RT / AUX / auxiliary systems) at all their
+//      nodes.  libMesh's default algebraic ghosting (send_list) covers the dofs of local elements only, so before
+//      es.init() call   rdc_gpu::add_ghost_layer(system)   for every system the callbacks read (the model system and,
+//      where used, "RIPF-TimeDeriv", "RT", "AUX", "SolidSystem::auxiliary"): it attaches a PointNeighborCoupling with one
+//      level to the system's DofMap, which puts those dofs into the ghosted vectors.  Without it sys.old_solution(dof)
+//      on such a node is an out-of-range read in opt mode (an assert in dbg).  Serial runs need nothing.
+//      The GPU of a rank is  node-local MPI rank % rdc_device_count()  (one rank per GPU).
+#include "libmesh/boundary_info.h"
 #include "libmesh/dof_map.h"
 #include "libmesh/elem.h"
 #include "libmesh/equation_systems.h"
 #include "libmesh/mesh_base.h"
 #include "libmesh/numeric_vector.h"
 #include "libmesh/petsc_matrix.h"
+#include "libmesh/point_neighbor_coupling.h"
 #include "libmesh/transient_system.h"
+
+#include "./solid_system.h"   // the reference's own header (src/solid_system.h): SolidSystemGPU derives from it
+#include "./utils.h"          // export_integers (src/utils.h:268)
 
 #include <map>
 #include <unordered_map>
@@ -36,6 +54,7 @@ namespace rdc_gpu {
 struct Binding {
   rdc_ctx* ctx = nullptr;
   std::vector<dof_id_type> local_to_global_node;   // local node id -> libMesh node id (owned first, then ghosts)
+  std::vector<dof_id_type> elem_ids;               // binding element -> libMesh element id (local elements + ghost layer)
   std::vector<PetscInt> row_ptr, col_glob;         // owned-row CSR with GLOBAL dof column ids
   std::vector<double> val, rhs, u_old;
   dof_id_type n_owned = 0;
@@ -44,6 +63,29 @@ struct Binding {
 static std::map<std::string, Binding> g_bindings;
 
 static void fail(rdc_ctx* c, const char* what) { libmesh_error_msg(std::string(what) + ": " + rdc_last_error(c)); }
+
+// N > 1 ranks: ghost the dofs of every element that shares a point with a local element (see the header, item 4).
+// Call before es.init() for every system the GPU callbacks read.
+void add_ghost_layer(System& sys) {
+  static std::vector<std::unique_ptr<PointNeighborCoupling>> keep;   // the DofMap stores a reference
+  keep.emplace_back(new PointNeighborCoupling());
+  keep.back()->set_n_levels(1);
+  sys.get_dof_map().add_algebraic_ghosting_functor(*keep.back());
+}
+
+// one rank per GPU: the device of this rank is its rank among the ranks of the same host
+static int device_of_this_rank(const Parallel::Communicator& comm) {
+  int ndev = 0;
+  if (rdc_device_count(&ndev) != RDC_OK || ndev <= 0) libmesh_error_msg(rdc_last_error(nullptr));
+  int local_rank = 0;
+#ifdef LIBMESH_HAVE_MPI
+  MPI_Comm node;
+  MPI_Comm_split_type(comm.get(), MPI_COMM_TYPE_SHARED, (int)comm.rank(), MPI_INFO_NULL, &node);
+  MPI_Comm_rank(node, &local_rank);
+  MPI_Comm_free(&node);
+#endif
+  return local_rank % ndev;
+}
 
 // Marshal the rank's partition once: owned nodes first, then ghost nodes; elements = every active
 // element touching an owned node (libMesh's active_local elements plus one ghost layer, which a
@@ -65,6 +107,7 @@ static Binding& bind(EquationSystems& es, const std::string& name, unsigned int 
     if (touches) elems.push_back(elem);
   }
   const int nen = (int)elems.front()->n_nodes();   // TET4 (4) or HEX8 (8), one type per mesh
+  for (const Elem* elem : elems) B.elem_ids.push_back(elem->id());
   for (const Elem* elem : elems)
     for (int i = 0; i < nen; i++) {
       const dof_id_type g = elem->node_id(i);
@@ -75,8 +118,7 @@ static Binding& bind(EquationSystems& es, const std::string& name, unsigned int 
   std::vector<double> xyz(3 * B.local_to_global_node.size());
   for (size_t l = 0; l < B.local_to_global_node.size(); l++)
     for (int d = 0; d < 3; d++) xyz[3 * l + d] = mesh.node_ref(B.local_to_global_node[l])(d);
-  int device = 0;  // one rank per GPU: e.g. local MPI rank
-  if (rdc_ctx_create(device, &B.ctx) != RDC_OK) libmesh_error_msg(rdc_last_error(nullptr));
+  if (rdc_ctx_create(device_of_this_rank(mesh.comm()), &B.ctx) != RDC_OK) libmesh_error_msg(rdc_last_error(nullptr));
   if (rdc_mesh_upload(B.ctx, nen, (int64_t)elems.size(), (int64_t)B.local_to_global_node.size(), B.n_owned, conn.data(),
                       xyz.data(), (int)nvar) != RDC_OK) fail(B.ctx, "rdc_mesh_upload");
   // pattern with LOCAL column ids -> global PETSc dof ids (dof_number(sys, var, 0))
@@ -209,9 +251,190 @@ void assemble_ripf(EquationSystems& es, const std::string& system_name) {
   push_results(es, system, B, 3);
 }
 
-// assemble_adpm / assemble_proteas_model: same pattern; the exact parameter marshalling (incl. the elemental
-// "Tracts" system -> RDC_FIELD_ELEM_TRACTS and the nodal "AUX" system -> RDC_FIELD_AUX_NODAL) is spelled out and
-// tested in rdcfes_amd/host/rdc_host.h::assemble_adpm / assemble_proteas_model.  SolidSystem: override
-// FEMSystem::assembly(get_residual, get_jacobian) with rdc_solid_assemble.
+// current_local_solution of any nodal system at the binding's nodes -> [local node][first..first+n) per node
+static void gather_nodal(const EquationSystems& es, const System& sys, const Binding& B, unsigned int first_var, unsigned int n,
+                         unsigned int stride, unsigned int offset, std::vector<double>& out) {
+  const MeshBase& mesh = es.get_mesh();
+  for (size_t l = 0; l < B.local_to_global_node.size(); l++) {
+    const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+    for (unsigned int v = 0; v < n; v++) out[l * stride + offset + v] = sys.current_solution(nd.dof_number(sys.number(), first_var + v, 0));
+  }
+}
+
+// src/adpm.C:324-652: unknowns PrP, A_b, Tau; the elemental "Tracts" system (3 CONSTANT MONOMIAL variables, :448-453)
+// becomes RDC_FIELD_ELEM_TRACTS; decay/PrP is scaled with system.time (:367-413)
+void assemble_adpm(EquationSystems& es, const std::string& system_name) {
+  TransientLinearImplicitSystem& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  libmesh_assert_equal_to(system.n_vars(), 3);
+  const System& tracts = es.get_system<System>("Tracts");
+  Binding& B = bind(es, system_name, 3);
+  auto R = [&](const std::string& k) { return es.parameters.get<Real>(k); };
+  rdc_adpm_params p;
+  p.time_step = R("time_step");
+  p.time = system.time;
+  p.decay_PrP_time_exponent = R("decay/PrP/time_exponent");
+  auto triple = [&](double* d, const std::string& key, const char* kind) {
+    d[0] = R(key); d[1] = R(key + "/" + kind + "/0"); d[2] = R(key + "/" + kind + "/1");
+  };
+  auto trapezoid = [&](double* d, const std::string& key) {
+    d[0] = R(key);
+    for (int i = 0; i < 4; i++) d[1 + i] = R(key + "/trapezoid/" + std::to_string(i));
+  };
+  triple(p.decay_PrP, "decay/PrP", "pulse");
+  trapezoid(p.transform_A_b, "transform/A_b"); trapezoid(p.transform_Tau, "transform/Tau");
+  triple(p.diffuse_A_b, "diffuse/A_b", "pulse"); triple(p.taxis1_A_b, "taxis_1/A_b", "pulse"); triple(p.taxis2_A_b, "taxis_2/A_b", "pulse");
+  triple(p.produce_A_b, "produce/A_b", "sigmoid"); triple(p.decay_A_b, "decay/A_b", "pulse");
+  triple(p.diffuse_Tau, "diffuse/Tau", "pulse"); triple(p.taxis1_Tau, "taxis_1/Tau", "pulse"); triple(p.taxis2_Tau, "taxis_2/Tau", "pulse");
+  triple(p.produce_Tau, "produce/Tau", "sigmoid"); triple(p.decay_Tau, "decay/Tau", "pulse");
+  p.taxis_A_b_angle = R("taxis/A_b/angle");   // already radians in es.parameters (src/adpm.C:193)
+  p.taxis_Tau_angle = R("taxis/Tau/angle");
+  // per-element tract vectors in the binding's element order
+  const MeshBase& mesh = es.get_mesh();
+  std::vector<double> tr(3 * B.elem_ids.size());
+  for (size_t e = 0; e < B.elem_ids.size(); e++) {
+    const Elem& elem = mesh.elem_ref(B.elem_ids[e]);
+    for (unsigned int d = 0; d < 3; d++) tr[3 * e + d] = tracts.current_solution(elem.dof_number(tracts.number(), d, 0));
+  }
+  gather_old_solution(es, system, B, 3);
+  if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
+  if (rdc_field_upload(B.ctx, RDC_FIELD_ELEM_TRACTS, tr.data(), (int64_t)tr.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(tracts)");
+  if (rdc_assemble_adpm(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_adpm");
+  push_results(es, system, B, 3);
+}
+
+// src/proteas.C:338-705: unknowns hos, tum, nec, vsc, oed; the nodal "AUX" system {HU, RTD} -> RDC_FIELD_AUX_NODAL
+// (only variable 0 is read by the assembly, at local node 1 of every element: src/proteas.C:472,481)
+void assemble_proteas_model(EquationSystems& es, const std::string& system_name) {
+  TransientLinearImplicitSystem& system = es.get_system<TransientLinearImplicitSystem>(system_name);
+  libmesh_assert_equal_to(system.n_vars(), 5);
+  const System& AUX = es.get_system<System>("AUX");
+  Binding& B = bind(es, system_name, 5);
+  auto R = [&](const char* k) { return es.parameters.get<Real>(k); };
+  rdc_proteas_params p;   // src/proteas.C:376-409
+  p.time_step = R("time_step");
+  p.cells_total_capacity = R("cells/total_capacity"); p.RT_max_dosage = R("radiotherapy/max_dosage");
+  p.host_proliferation = R("host/proliferation"); p.host_vsc_threshold = R("host/vsc_threshold");
+  p.host_RT_death_rate = R("host/RT_death_rate"); p.host_RT_exp_a = R("host/RT_exp_a"); p.host_RT_exp_b = R("host/RT_exp_b");
+  p.host_necrosis_rate = R("host/necrosis_rate");
+  p.tumour_diffusion = R("tumour/diffusion"); p.tumour_diffusion_host = R("tumour/diffusion_host");
+  p.tumour_proliferation = R("tumour/proliferation"); p.tumour_vsc_threshold = R("tumour/vsc_threshold");
+  p.tumour_RT_death_rate = R("tumour/RT_death_rate"); p.tumour_RT_exp_a = R("tumour/RT_exp_a"); p.tumour_RT_exp_b = R("tumour/RT_exp_b");
+  p.tumour_necrosis_rate = R("tumour/necrosis_rate");
+  p.necrosis_clearance = R("necrosis/clearance"); p.necrosis_slope = R("necrosis/slope"); p.necrosis_vsc_threshold = R("necrosis/vsc_threshold");
+  p.vascular_proliferation = R("vascular/proliferation"); p.vascular_necrosis_rate = R("vascular/necrosis_rate");
+  p.oedema_diffusion = R("oedema/diffusion"); p.oedema_proliferation = R("oedema/proliferation"); p.oedema_vsc_threshold = R("oedema/vsc_threshold");
+  p.oedema_RT_coeff = R("oedema/RT_coeff"); p.oedema_RT_exp = R("oedema/RT_exp"); p.oedema_reabsorption_rate = R("oedema/reabsorption_rate");
+  std::vector<double> aux(3 * B.local_to_global_node.size(), 0.0);
+  gather_nodal(es, AUX, B, 0, 2, 3, 0, aux);
+  gather_old_solution(es, system, B, 5);
+  if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
+  if (rdc_field_upload(B.ctx, RDC_FIELD_AUX_NODAL, aux.data(), (int64_t)aux.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(aux)");
+  if (rdc_assemble_proteas(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_proteas");
+  push_results(es, system, B, 5);
+}
+
+// ---- SolidSystem: FEMSystem::assembly() replaced wholesale -------------------------------------------------------
+// libMesh's FEMSystem::assembly(get_residual, get_jacobian, ...) zeroes rhs / matrix, loops over the local elements
+// (and their boundary sides) calling the reference's element_time_derivative / side_time_derivative virtuals
+// (src/solid_system.C:146-371) and adds each element's residual and Jacobian into the global ones.  Here the loop is
+// ONE GPU call on data marshalled from exactly what those virtuals read.  NewtonSolver, the PETSc linear solve,
+// SolidSystem::update() (moves the mesh), run_solver / post_process / update_data stay the reference's code.
+class SolidSystemGPU : public SolidSystem {
+ public:
+  SolidSystemGPU(EquationSystems& es, std::string name, unsigned int number) : SolidSystem(es, name, number) {}
+
+  virtual void assembly(bool get_residual, bool get_jacobian, bool /*apply_heterogeneous_constraints*/ = false,
+                        bool /*apply_no_constraints*/ = false) override {
+    EquationSystems& es = this->get_equation_systems();
+    const MeshBase& mesh = es.get_mesh();
+    Binding& B = bind(es, this->name(), 3);
+    const System& aux = es.get_system<System>("SolidSystem::auxiliary");
+    const System& fibre = es.get_system<System>("SolidSystem::fibre");
+    const size_t nn = B.local_to_global_node.size(), ne = B.elem_ids.size();
+    if (!solid_bound_) {   // what does not change between Newton iterations
+      // subdomain -> material table ("material/<id>/Hyperelastic/...", src/solid_system.C:183-190)
+      std::map<subdomain_id_type, int32_t> index;
+      std::vector<rdc_solid_material> table;
+      std::vector<int32_t> em(ne);
+      for (size_t e = 0; e < ne; e++) {
+        const subdomain_id_type id = mesh.elem_ref(B.elem_ids[e]).subdomain_id();
+        auto it = index.find(id);
+        if (it == index.end()) {
+          const std::string k = "material/" + std::to_string(id) + "/Hyperelastic/";
+          rdc_solid_material m;
+          m.Young = es.parameters.get<Real>(k + "Young"); m.Poisson = es.parameters.get<Real>(k + "Poisson");
+          m.FibreStiffness = es.parameters.get<Real>(k + "FibreStiffness");
+          for (int d = 0; d < 3; d++) m.rate[d] = es.parameters.get<Real>(k + "VolumetricStretchRatio/rate_" + std::to_string(d));
+          it = index.emplace(id, (int32_t)table.size()).first;
+          table.push_back(m);
+        }
+        em[e] = it->second;
+      }
+      if (rdc_solid_set_materials(B.ctx, em.data(), (int32_t)table.size(), table.data()) != RDC_OK) fail(B.ctx, "rdc_solid_set_materials");
+      // boundary sides whose id is in "BCs" (src/solid_system.C:294-306) of EVERY element of the binding, ghost layer
+      // included: the library adds a side's penalty terms only into rows of nodes this rank owns, so each rank ends up
+      // with the complete rows of its nodes (a side next to the partition boundary is listed on both ranks)
+      const std::set<int> bcs = export_integers(es.parameters.get<std::string>("BCs"));
+      std::vector<int64_t> se;
+      std::vector<int32_t> si;
+      std::vector<double> sd;
+      for (int bc : bcs) {
+        const Point u = es.parameters.get<Point>("BC/" + std::to_string(bc) + "/displacement");
+        for (size_t e = 0; e < ne; e++) {
+          const Elem& elem = mesh.elem_ref(B.elem_ids[e]);
+          for (auto s : elem.side_index_range())
+            if (mesh.get_boundary_info().has_boundary_id(&elem, s, cast_int<boundary_id_type>(bc))) {
+              se.push_back((int64_t)e); si.push_back((int32_t)s);
+              for (int d = 0; d < 3; d++) sd.push_back(u(d));
+            }
+        }
+      }
+      if (rdc_solid_set_sides(B.ctx, (int64_t)se.size(), se.data(), si.data(), sd.data()) != RDC_OK) fail(B.ctx, "rdc_solid_set_sides");
+      solid_bound_ = true;
+    }
+    // current node positions = the unknowns of the current Newton iterate (FEMContext::pre_fe_reinit moves the element's
+    // nodes there); undeformed positions; reference fibre
+    std::vector<double> x(3 * nn), X(3 * nn), eta(3 * ne);
+    for (size_t l = 0; l < nn; l++) {
+      const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+      for (unsigned int d = 0; d < 3; d++) {
+        x[3 * l + d] = this->current_solution(nd.dof_number(this->number(), this->var[d], 0));
+        X[3 * l + d] = aux.current_solution(nd.dof_number(aux.number(), this->undefo_var[d], 0));   // :221-229
+      }
+    }
+    for (size_t e = 0; e < ne; e++) {
+      const Elem& elem = mesh.elem_ref(B.elem_ids[e]);
+      for (unsigned int d = 0; d < 3; d++) eta[3 * e + d] = fibre.current_solution(elem.dof_number(fibre.number(), d, 0));   // :204-216
+    }
+    if (rdc_mesh_update_coords(B.ctx, x.data()) != RDC_OK) fail(B.ctx, "rdc_mesh_update_coords");
+    if (rdc_field_upload(B.ctx, RDC_FIELD_UNDEFORMED_XYZ, X.data(), (int64_t)X.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(undeformed)");
+    if (rdc_field_upload(B.ctx, RDC_FIELD_ELEM_FIBRE, eta.data(), (int64_t)eta.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(fibre)");
+    rdc_solid_params p;
+    p.pseudo_time = es.parameters.get<Real>("pseudo_time");
+    p.displacement_penalty = es.parameters.get<Real>("BCs/displacement_penalty");
+    p.use_symmetry = es.parameters.get<bool>("solver/assembly_use_symmetry") ? 1 : 0;
+    p._pad = 0;
+    if (rdc_solid_assemble(B.ctx, &p, get_jacobian ? 1 : 0) != RDC_OK) fail(B.ctx, "rdc_solid_assemble");
+    if (rdc_csr_download(B.ctx, get_jacobian ? B.val.data() : nullptr, B.rhs.data()) != RDC_OK) fail(B.ctx, "rdc_csr_download");
+    // owned rows -> system.matrix / system.rhs (FEMSystem::assembly zeroes them first; complete rows: no stash traffic)
+    if (get_residual) this->rhs->zero();
+    if (get_jacobian) this->matrix->zero();
+    Mat A = get_jacobian ? cast_ref<PetscMatrix<Number>&>(*this->matrix).mat() : nullptr;
+    for (dof_id_type l = 0; l < B.n_owned; l++) {
+      const Node& nd = mesh.node_ref(B.local_to_global_node[l]);
+      for (unsigned int a = 0; a < 3; a++) {
+        const PetscInt row = (PetscInt)nd.dof_number(this->number(), this->var[a], 0);
+        const PetscInt r = (PetscInt)(l * 3 + a), b = B.row_ptr[r], n = B.row_ptr[r + 1] - b;
+        if (get_jacobian) MatSetValues(A, 1, &row, n, &B.col_glob[b], &B.val[b], INSERT_VALUES);
+        if (get_residual) this->rhs->set(row, B.rhs[r]);
+      }
+    }
+    if (get_residual) this->rhs->close();
+    if (get_jacobian) this->matrix->close();
+  }
+
+ private:
+  bool solid_bound_ = false;
+};
 
 }  // namespace rdc_gpu

@@ -17,6 +17,7 @@ ctx_p = C.c_void_p
 # name -> (restype, argtypes): every symbol include/rdc_assembly.h declares
 SIGNATURES = {
     "rdc_abi_version": (C.c_int, []),
+    "rdc_device_count": (C.c_int, [P(C.c_int)]),
     "rdc_ctx_create": (C.c_int, [C.c_int, P(ctx_p)]),
     "rdc_ctx_destroy": (C.c_int, [ctx_p]),
     "rdc_last_error": (C.c_char_p, [ctx_p]),

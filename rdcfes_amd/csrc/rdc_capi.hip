@@ -355,6 +355,14 @@ int rdc_abi_version(void) { return RDC_ABI_VERSION; }
 
 const char* rdc_last_error(const rdc_ctx* ctx) { return ctx ? ctx->err : g_create_error; }
 
+int rdc_device_count(int* n) {
+  if (!n) return RDC_ERR_INVALID;
+  int ndev = 0;
+  const hipError_t e = hipGetDeviceCount(&ndev);
+  *n = e == hipSuccess ? ndev : 0;
+  return e == hipSuccess ? RDC_OK : fail(nullptr, RDC_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+}
+
 int rdc_ctx_create(int device_ordinal, rdc_ctx** out) {
   if (!out) return fail(nullptr, RDC_ERR_INVALID, "null output pointer");
   *out = nullptr;
