@@ -29,6 +29,8 @@ SOURCES = [
     "rdc_model_adpm.hip",
     "rdc_model_proteas.hip",
     "rdc_tet4_fast.hip",
+    "rdc_tet4_ev.hip",
+    "rdc_prep_ev.cpp",
     "rdc_solid.hip",
 ]
 

@@ -1,13 +1,16 @@
 // rdc_capi.hip — implementation of the C-ABI declared in include/rdc_assembly.h.
 // No CPU fallback lives here: every assemble call launches HIP kernels or fails.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "rdc_internal.h"
 #include "rdc_tet4_pihna_moments.h"
+#include "rdc_tet4_ev.h"
 #include "rdc_solid.h"
 
 using namespace rdc;
@@ -47,6 +50,12 @@ struct rdc_ctx {
   int opt_slim = 0;     // PIHNA: slim per-point state (re-derived per equation row); with occupancy=3 three waves per SIMD
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
+  HostPrepEv prep_ev;          // element-visit lists (PIHNA TET4, shipped pattern); .ok = available
+  DevBuf ev_desc, ev_nlist, ev_vloc, ev_vslot, ev_ntab, ev_btab, ev_perm;
+  int64_t ev_perm_interior = -2;   // "interior_nodes" value the uploaded workgroup order was built for
+  int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
+  int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
+  int opt_ev_lds = 54000;          // LDS bytes per workgroup the clusters are sized for (3 workgroups per CU)
   // device mesh data
   DevBuf conn, xyz, bptr, eslot, elem_order, first_mask, first_rhs, pair_elem, pair_local, node_pair_ptr,
       wg_node_ptr;
@@ -200,6 +209,8 @@ hipError_t launch_specialised(const LaunchArgs& a, const typename M::K& k, const
 template <>
 hipError_t launch_specialised<Pihna, rdc_pihna_params>(const LaunchArgs& a, const Pihna::K& k, const rdc_pihna_params& p) {
   if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && PihnaNoCellTransport::applies(p)) {
+    // default: one thread per element visit, moments accumulated per node block (rdc_tet4_ev.hip)
+    if (a.use_ev && a.ev.n_wg > 0 && a.strategy == RDC_SCATTER_ROWGATHER) return launch_tet4_ev(a, k);
     if (a.opt_slim && a.exp_mode == 3) return launch_tet4_fast<PihnaNoCellTransportSlim>(a, k);
     if (a.opt_moments) return launch_tet4_fast<PihnaNoCellTransportMoments>(a, k);  // same sums, moment form
     return launch_tet4_fast<PihnaNoCellTransport>(a, k);
@@ -223,6 +234,26 @@ template <>
 hipError_t launch_specialised<Adpm, rdc_adpm_params>(const LaunchArgs& a, const Adpm::K& k, const rdc_adpm_params& p) {
   if (a.variant != RDC_VARIANT_GENERIC && a.opt_special && AdpmDecayOnly::applies(p)) return launch_rd<AdpmDecayOnly>(a, k);
   return launch_rd<Adpm>(a, k);
+}
+
+template <class P> bool pihna_pattern_applies(const P*) { return false; }
+template <> bool pihna_pattern_applies<rdc_pihna_params>(const rdc_pihna_params* p) { return PihnaNoCellTransport::applies(*p); }
+
+// two-part assembly on the element-visit lists: (re)builds the workgroup order for the current "interior_nodes":
+// clusters all of whose nodes are below it first
+int ev_order_for_interior(rdc_ctx* c) {
+  if (c->ev_perm_interior == c->opt_interior && c->ev_perm.p) return RDC_OK;
+  const std::vector<HostPrepEv::Desc>& D = c->prep_ev.desc;
+  std::vector<uint32_t> perm;
+  perm.reserve(D.size());
+  for (size_t w = 0; w < D.size(); w++) if ((int64_t)D[w].max_node < c->opt_interior) perm.push_back((uint32_t)w);
+  c->ev_part1_wg = (int)perm.size();
+  for (size_t w = 0; w < D.size(); w++) if (!((int64_t)D[w].max_node < c->opt_interior)) perm.push_back((uint32_t)w);
+  int rc = dev_upload(c, c->ev_perm, perm);
+  if (rc) return rc;
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  c->ev_perm_interior = c->opt_interior;
+  return RDC_OK;
 }
 
 // two-part assembly: number of leading row-gather workgroups whose nodes all lie inside [0, interior_nodes)
@@ -304,6 +335,43 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
     a.rg2.block = c->prep.rg2_block;
   }
+  // element-visit kernel: default for the shipped-pattern PIHNA / TET4 ("kernel" = 0 or 7); the diagnostic knobs of the
+  // pair kernels (ablate, stamps, slim, coefficient form, occupancy 1) and "kernel" = 5 select k_tet4_rg5 instead
+  a.use_ev = c->prep_ev.ok && (c->opt_kernel == 0 || c->opt_kernel == 7) && c->opt_moments && !c->opt_slim && !c->opt_ablate &&
+             !c->stamps.p && c->opt_occ != 1 && c->opt_ldspad == 0;
+  a.opt_ev_occ = c->opt_ev_occ;
+  if (c->opt_kernel == 5 || c->opt_kernel == 7) a.opt_kernel = 0;
+  if (a.use_ev) {
+    a.ev.n_wg = (int)c->prep_ev.desc.size();
+    a.ev.desc = (const HostPrepEv::Desc*)c->ev_desc.p;
+    a.ev.nlist = (const uint32_t*)c->ev_nlist.p;
+    a.ev.vloc = (const uint32_t*)c->ev_vloc.p;
+    a.ev.vslot = (const uint32_t*)c->ev_vslot.p;
+    a.ev.ntab = (const HostPrepEv::Node*)c->ev_ntab.p;
+    a.ev.btab = (const uint16_t*)c->ev_btab.p;
+    a.ev.nls = c->prep_ev.nls;
+    a.ev.max_out_doubles = c->prep_ev.max_out_doubles;
+  }
+  const bool ev_path = a.use_ev && std::is_same<M, Pihna>::value && a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && c->opt_special &&
+                       a.strategy == RDC_SCATTER_ROWGATHER && pihna_pattern_applies(p);
+  if (c->opt_part != 0 && ev_path) {
+    // two-part assembly on the element-visit lists: the clusters all of whose nodes are interior run in part 1
+    if (c->opt_interior < 0) return fail(c, RDC_ERR_STATE, "\"part\" needs \"interior_nodes\"");
+    if ((rc = ev_order_for_interior(c))) return rc;
+    a.ev.wg_perm = (const uint32_t*)c->ev_perm.p;
+    if (c->opt_part == 1) {
+      c->part1_packed = false;
+      if (c->ev_part1_wg == 0) return RDC_OK;
+      a.ev.wg_begin = 0; a.ev.wg_count = c->ev_part1_wg;
+      if (!c->pack_event) RDC_HIP(c, hipEventCreateWithFlags(&c->pack_event, hipEventDisableTiming));
+      a.pack_part = 1; a.pack_event = c->pack_event;
+      c->part1_packed = true;
+    } else {
+      a.ev.wg_begin = c->ev_part1_wg; a.ev.wg_count = -1;
+      if (c->part1_packed) { a.pack_part = 2; a.pack_event = c->pack_event; }
+      c->part1_packed = false;
+    }
+  } else
   if (c->opt_part != 0) {
     // two-part assembly (halo overlap): part 1 = the leading workgroups whose nodes are all interior, part 2 = the
     // rest.  Only the default TET4 row-gather kernel launches sub-ranges; every other path assembles everything in
@@ -396,7 +464,8 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg4_wgntab, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
-                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot};
+                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot,
+                   &c->ev_desc, &c->ev_nlist, &c->ev_vloc, &c->ev_vslot, &c->ev_ntab, &c->ev_btab, &c->ev_perm};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -464,6 +533,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     if (value != 0 && value != 1) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (two-pass) or 1 (coloured)");
     c->opt_solid_kernel = value;
   }
+  else if (!std::strcmp(key, "ev_occupancy")) c->opt_ev_occ = value;   // element-visit kernel: 3 (default, 168 registers) or 2
+  else if (!std::strcmp(key, "ev_lds")) c->opt_ev_lds = value;   // LDS bytes per workgroup the element-visit clusters are sized for (next rdc_mesh_upload)
   else if (!std::strcmp(key, "kernel")) c->opt_kernel = value;  // 0 = default (LDS-staged node records, k_tet4_rg5), 3 = k_tet4_rg3, 4 = persistent k_tet4_rg4, 6 = k_tet4_rg6 (rg5 over work items with a tail prefetch, experimental),
                                                                  // 1 = first row-gather kernel, 2 = staged deterministic k_tet4_rg2
   else return fail(c, RDC_ERR_INVALID, "unknown option '%s'", key);
@@ -520,6 +591,25 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
       if ((rc = dev_upload(c, c->rg4_nlist, P.nlist))) return rc;
       if ((rc = dev_upload(c, c->rg4_wgntab, P.wg_ntab))) return rc;
       if ((rc = dev_upload(c, c->rg4_ploc, P.pair_loc))) return rc;
+    }
+  }
+  c->prep_ev = HostPrepEv();
+  c->ev_perm_interior = -2;
+  if (elem_type == RDC_TET4 && nvar == 5 && P.rg2_ok) {
+    // element-visit lists of the PIHNA kernel; a mesh they cannot describe simply keeps the pair kernels
+    const std::string ev_err = prep_build_ev(P, conn, (size_t)c->opt_ev_lds, c->prep_ev);
+    if (ev_err.empty()) {
+      if ((rc = dev_upload(c, c->ev_desc, c->prep_ev.desc))) return rc;
+      if ((rc = dev_upload(c, c->ev_nlist, c->prep_ev.nlist))) return rc;
+      if ((rc = dev_upload(c, c->ev_vloc, c->prep_ev.vloc))) return rc;
+      if ((rc = dev_upload(c, c->ev_vslot, c->prep_ev.vslot))) return rc;
+      if ((rc = dev_upload(c, c->ev_ntab, c->prep_ev.ntab))) return rc;
+      if ((rc = dev_upload(c, c->ev_btab, c->prep_ev.btab))) return rc;
+      // the big host copies are not needed again (the descriptors are: two-part order)
+      std::vector<uint32_t>().swap(c->prep_ev.nlist); std::vector<uint32_t>().swap(c->prep_ev.vloc);
+      std::vector<uint32_t>().swap(c->prep_ev.vslot); std::vector<uint16_t>().swap(c->prep_ev.btab);
+    } else {
+      c->prep_ev = HostPrepEv();
     }
   }
   const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
@@ -819,6 +909,15 @@ int rdc_part1_nodes(const rdc_ctx* c, int64_t* n_nodes) {
   if (!c || !n_nodes) return RDC_ERR_INVALID;
   if (!c->have_mesh) return RDC_ERR_STATE;
   *n_nodes = 0;
+  if (c->opt_interior >= 0 && c->prep_ev.ok && (c->opt_kernel == 0 || c->opt_kernel == 7)) {
+    // element-visit lists: clusters are not node ranges; the rows of [0, n) are complete after part 1 when no cluster
+    // with a node below n reaches up to "interior_nodes"
+    int64_t n = c->opt_interior;
+    for (const HostPrepEv::Desc& d : c->prep_ev.desc)
+      if (!((int64_t)d.max_node < c->opt_interior)) n = std::min<int64_t>(n, (int64_t)d.min_node);
+    *n_nodes = n;
+    return RDC_OK;
+  }
   if (c->opt_interior < 0 || !c->prep.rg2_ok || c->prep.nen != 4 || c->prep.wg2.empty()) return RDC_OK;
   const int split = part1_workgroups(c);
   if (split > 0) *n_nodes = (int64_t)c->prep.wg2[(size_t)split - 1].n0 + c->prep.wg2[(size_t)split - 1].nnodes;

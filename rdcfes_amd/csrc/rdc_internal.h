@@ -33,6 +33,21 @@ struct Rg2Dev {
   int block = 256;
 };
 
+// device view of the element-visit work lists (HostPrepEv)
+struct EvDev {
+  int n_wg = 0;
+  const HostPrepEv::Desc* desc = nullptr;
+  const uint32_t* nlist = nullptr;
+  const uint32_t* vloc = nullptr;
+  const uint32_t* vslot = nullptr;
+  const HostPrepEv::Node* ntab = nullptr;
+  const uint16_t* btab = nullptr;
+  const uint32_t* wg_perm = nullptr;   // two-part assembly: workgroup order with the interior clusters first (else null)
+  int wg_begin = 0, wg_count = -1;
+  int nls = 0;
+  size_t max_out_doubles = 0;
+};
+
 // ---- kernel launch plumbing -----------------------------------------------------------------
 struct LaunchArgs {
   MeshDev m;
@@ -52,6 +67,9 @@ struct LaunchArgs {
   int variant;     // RDC_VARIANT_*
   int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf, opt_slim = 0, opt_moments = 1, opt_stagger = 0, opt_ldspad = 0;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
+  EvDev ev;
+  bool use_ev = false;   // element-visit kernel allowed for this call
+  int opt_ev_occ = 3;
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;
   double* rhs;
@@ -68,6 +86,10 @@ hipError_t launch_rd(const LaunchArgs& a, const typename M::K& k);
 // TET4-specialised factored kernels (rdc_tet4_fast.hip)
 template <class M>
 hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k);
+// node records of the PIHNA kernels (xyz | u, 64 bytes per node), honouring the two-part pack rules (rdc_tet4_fast.hip)
+hipError_t pack_nodes_pihna(const LaunchArgs& a);
+// element-visit / moment kernel of the shipped-pattern PIHNA TET4 assembly (rdc_tet4_ev.hip)
+hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k);
 
 }  // namespace rdc
 #endif

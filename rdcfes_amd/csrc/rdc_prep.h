@@ -100,6 +100,36 @@ struct SolidGather {
 };
 std::string solid_gather_build(const HostPrep& P, SolidGather& out);
 
+// ---- work lists of the element-visit / moment kernel (rdc_tet4_ev.hip; TET4, 5 unknowns) --------------------------
+// A workgroup owns a CLUSTER of <= 16 owned nodes and visits every element that touches it (<= 256) once.
+struct HostPrepEv {
+  static constexpr int MAXN = 16, NBP = 256, BLOCK = 256;
+  struct Desc {            // 32 bytes per workgroup
+    uint32_t nown, nvis, ntouch, nb;   // owned nodes, element visits, distinct nodes of the visits, node blocks of the owned rows
+    uint32_t out_doubles;              // size of the CSR image of the cluster's rows in LDS (doubles, incl. phase padding)
+    uint32_t min_node, max_node, pad;  // smallest / largest owned node id (two-part assembly)
+  };
+  struct Node {            // 16 bytes per owned node of a workgroup
+    uint32_t bptr;         // first node block of the node's rows (CSR value offset = nvar^2 * bptr)
+    uint16_t len, blk0;    // node blocks in the row; first block of the node inside the workgroup's moment slice
+    uint32_t obase;        // offset of the node's CSR segment inside the LDS image (same 16-byte phase as in memory)
+    uint32_t node;         // node id
+  };
+  bool ok = false;
+  int nls = 0;                       // node list stride (multiple of 64)
+  size_t max_out_doubles = 0;
+  std::vector<Desc> desc;
+  std::vector<uint32_t> nlist;       // [n_wg][nls] node ids, the owned ones first, padded with the first
+  std::vector<uint32_t> vloc;        // [n_wg][256] four 8-bit list positions of the visit's vertices, owned first; ~0u = none
+  std::vector<uint32_t> vslot;       // [n_wg][256][4]: byte j of word i = column slot of vertex j in the row of vertex i
+  std::vector<Node> ntab;            // [n_wg][16]
+  std::vector<uint16_t> btab;        // [n_wg][256] node block -> owner (low byte: owned-node index, high byte: slot in its row)
+  // statistics: element visits and (row, visit) pairs over all workgroups
+  int64_t n_visits = 0, n_rows = 0;
+};
+// needs P.bptr / P.bcol / P.eslot of prep_build; lds_budget = LDS bytes a workgroup may use (3 workgroups per CU: 53 KB)
+std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& out);
+
 // returns empty string on success, else an error message
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,
                        int nvar, size_t lds_budget_bytes, int block, HostPrep& out, bool conflict_aware = true);

@@ -1,0 +1,166 @@
+// rdc_tet4_ev.hip — element-visit / moment-accumulation kernel of the PIHNA TET4 assembly (shipped parameter pattern).
+// See rdc_tet4_ev.h for the formulation and rdc_prep_ev.cpp for the work lists.
+//
+// One workgroup = one CLUSTER of <= 16 owned nodes (not necessarily consecutive ids) and the <= 256 elements touching it.
+//   phase 0  zero the moment slice, load the lists, LDS-DMA the node records of the cluster's closure      (as k_tet4_rg5)
+//   phase 1  one thread per element visit: pihna_visit() -> ds_add_f64 of the moments of the rows it owns
+//   phase 2  one thread per node block: 16 moments -> 25 matrix entries (pihna_expand), written to an LDS image of the
+//            CSR rows of the cluster's nodes; rhs entries straight to memory
+//   phase 3  the image leaves with 16-byte non-temporal stores, one contiguous CSR segment per node
+// Every CSR value is written exactly once; no global atomics, no colours.  Sums are order-dependent in the last bits.
+#include "rdc_internal.h"
+#include "rdc_tet4_ev.h"
+
+namespace rdc {
+
+template <class M> struct RecEv {
+  static constexpr int RAW = 3 + M::NV + M::NAUX;
+  static constexpr int N = (RAW + 1) & ~1;
+};
+
+struct EvSink {
+  double* p[4][4];   // LDS address of moment 0 of block (node i, node j)
+  double* pr[4];     // LDS address of rhs entry 0 of node i
+  __device__ __forceinline__ void mom(int m, int i, int j, double v) {
+    __hip_atomic_fetch_add(p[i][j] + m * ev::NBP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void rhs(int a, int i, double v) {
+    __hip_atomic_fetch_add(pr[i] + a * ev::MAXN, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+};
+
+template <int EXP_MODE, int MINW>
+__global__ void __launch_bounds__(256, MINW)
+k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
+          const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint16_t* __restrict__ btab,
+          const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
+          double* __restrict__ rhs, const int nls, const int wg_begin) {
+  constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
+  constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP | R: 5 x MAXN | records: NP x nls x 16 B]
+  __shared__ HostPrepEv::Node snode[MAXN];
+  __shared__ uint16_t sbt[NBP];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  int w = (int)blockIdx.x + wg_begin;
+  if (wg_perm) w = (int)wg_perm[w];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double* const R = lds + NM * NBP;
+  double* const recs = R + 5 * MAXN;
+  // phase 0: zero [M | R] (16-byte stores), list loads, LDS-DMA of the node records
+  {
+    double2* z = reinterpret_cast<double2*>(lds);
+    for (int x = tid; x < (NM * NBP + 5 * MAXN) / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);
+  }
+  const int rounds = nls >> 6;
+  uint32_t nid = 0;
+  if (wv < rounds) nid = nlist[(size_t)w * nls + wv * 64 + lane];
+  const uint32_t pl = vloc[(size_t)w * BLOCK + tid];
+  const uint4 sl = reinterpret_cast<const uint4*>(vslot)[(size_t)w * BLOCK + tid];
+  const HostPrepEv::Desc d = desc[w];
+  if (tid < MAXN) snode[tid] = ntab[(size_t)w * MAXN + tid];
+  sbt[tid] = btab[(size_t)w * NBP + tid];
+  if (wv < rounds) {
+    const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(recs + (p * nls + wv * 64) * 2), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // phase 1: element visits
+  if (pl != 0xFFFFFFFFu) {
+    double X[4][3], U[4][5];
+    int li[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      li[j] = (pl >> (8 * j)) & 0xFF;
+      double rr[2 * NP];
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        const double2 v2 = reinterpret_cast<const double2*>(recs)[p * nls + li[j]];
+        rr[2 * p] = v2.x; rr[2 * p + 1] = v2.y;
+      }
+      X[j][0] = rr[0]; X[j][1] = rr[1]; X[j][2] = rr[2];
+#pragma unroll
+      for (int v = 0; v < 5; v++) U[j][v] = rr[3 + v];
+    }
+    const int nown = (int)d.nown;
+    // the owned vertices come first: r = number of list positions below nown
+    const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
+    EvSink sink;
+    const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int b0 = (i < r) ? (int)snode[i < r ? li[i] : 0].blk0 : 0;
+      sink.pr[i] = R + ((i < r) ? li[i] : 0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + b0 + (int)((sw[i] >> (8 * j)) & 0xFF);
+    }
+    ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
+  }
+  __syncthreads();
+  // phase 2: node block tid: moments -> entries
+  const int nb = (int)d.nb;
+  double e[NM];
+  const bool has = tid < nb;
+  if (has) {
+#pragma unroll
+    for (int m = 0; m < NM; m++) e[m] = lds[m * NBP + tid];
+  }
+  if (tid < (int)d.nown * 5) {   // rhs: R[a][node] -> rhs[node * 5 + a]
+    const int n = tid / 5, a = tid - n * 5;
+    rhs[(size_t)snode[n].node * 5 + a] = R[a * MAXN + n];
+  }
+  __syncthreads();   // every moment has been read: the image may overwrite the slice
+  if (has) {
+    double o[25];
+    ev::pihna_expand(k, e, o);
+    const uint32_t bt = sbt[tid];
+    const int n = (int)(bt & 0xFF), s = (int)(bt >> 8);
+    const int len5 = 5 * (int)snode[n].len;
+    double* dst = lds + snode[n].obase + 5 * s;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+      for (int b = 0; b < 5; b++) dst[a * len5 + b] = o[a * 5 + b];
+  }
+  __syncthreads();
+  // phase 3: one contiguous CSR segment per node; the image has the 16-byte phase of its segment in memory
+  for (int n = wv; n < (int)d.nown; n += 4) {
+    const HostPrepEv::Node nd = snode[n];
+    const int cnt = 25 * (int)nd.len;
+    double* out = val + (size_t)25 * nd.bptr;            // out[x] <-> img[x]
+    const double* img = lds + nd.obase;
+    const int sh = (int)(nd.obase & 1);                  // == (25 * bptr) & 1 by construction
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    const int npair = (cnt - sh) >> 1;
+    const v2d_t* src = reinterpret_cast<const v2d_t*>(img + sh);
+    v2d_t* dstg = reinterpret_cast<v2d_t*>(out + sh);
+    for (int x = lane; x < npair; x += 64) __builtin_nontemporal_store(src[x], dstg + x);
+    if (sh && lane == 0) __builtin_nontemporal_store(img[0], out);
+    if (((cnt - sh) & 1) && lane == 1) __builtin_nontemporal_store(img[cnt - 1], out + cnt - 1);
+  }
+}
+
+hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
+  const EvDev& E = a.ev;
+  // node records (same pack kernel and two-part rules as the pair kernels)
+  hipError_t e = pack_nodes_pihna(a);
+  if (e != hipSuccess) return e;
+  if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
+  const int wg_count = E.wg_count < 0 ? E.n_wg - E.wg_begin : E.wg_count;
+  if (wg_count <= 0) return hipSuccess;
+  const size_t acc = (size_t)ev::NM * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
+  const size_t lds_doubles = acc > E.max_out_doubles ? acc : E.max_out_doubles;
+  const size_t lds_bytes = lds_doubles * sizeof(double);
+#define RDC_EV(MODE, MINW)                                                                                          \
+  hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
+                     E.vslot, E.ntab, E.btab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+  if (a.exp_mode == 3) { if (a.opt_ev_occ == 2) RDC_EV(3, 2); else RDC_EV(3, 3); }
+  else { if (a.opt_ev_occ == 2) RDC_EV(0, 2); else RDC_EV(0, 3); }
+#undef RDC_EV
+  return hipGetLastError();
+}
+
+}  // namespace rdc

@@ -900,24 +900,32 @@ k_tet4_coloured(const MeshDev m, const typename M::K k, int64_t first, int64_t c
   }
 }
 
+// Node records.  Two-part assembly (rdc_assembly.h, "part"): part 1 packs only the OWNED nodes -- its rows read
+// nothing else, and the ghost rows of u may be being rewritten by the halo exchange on another stream -- and
+// records an event; part 2 (possibly on another stream) waits for that event, packs only the GHOST nodes and then
+// reads both.  No record is written while a kernel of the other part may read it.
+template <class M>
+static hipError_t pack_nodes(const LaunchArgs& a) {
+  int64_t nb = 0, ne = a.m.n_node;
+  if (a.pack_part == 1) ne = a.m.n_owned;
+  else if (a.pack_part == 2) { nb = a.m.n_owned; if (a.pack_event) (void)hipStreamWaitEvent(a.stream, a.pack_event, 0); }
+  const int64_t total = (ne - nb) * Rec<M>::N;
+  if (total > 0) {
+    int64_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux, a.packed);
+  }
+  if (a.pack_part == 1 && a.pack_event) (void)hipEventRecord(a.pack_event, a.stream);
+  return hipGetLastError();
+}
+
+hipError_t pack_nodes_pihna(const LaunchArgs& a) { return pack_nodes<Pihna>(a); }
+
 template <class M, int EXP_MODE>
 static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) {
-  // Node records.  Two-part assembly (rdc_assembly.h, "part"): part 1 packs only the OWNED nodes -- its rows read
-  // nothing else, and the ghost rows of u may be being rewritten by the halo exchange on another stream -- and
-  // records an event; part 2 (possibly on another stream) waits for that event, packs only the GHOST nodes and then
-  // reads both.  No record is written while a kernel of the other part may read it.
   {
-    int64_t nb = 0, ne = a.m.n_node;
-    if (a.pack_part == 1) ne = a.m.n_owned;
-    else if (a.pack_part == 2) { nb = a.m.n_owned; if (a.pack_event) (void)hipStreamWaitEvent(a.stream, a.pack_event, 0); }
-    const int64_t total = (ne - nb) * Rec<M>::N;
-    if (total > 0) {
-      int64_t grid = (total + 255) / 256;
-      if (grid > 4096) grid = 4096;
-      hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux,
-                         a.packed);
-    }
-    if (a.pack_part == 1 && a.pack_event) (void)hipEventRecord(a.pack_event, a.stream);
+    const hipError_t pe = pack_nodes<M>(a);
+    if (pe != hipSuccess) return pe;
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);

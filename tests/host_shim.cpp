@@ -9,6 +9,7 @@
 #include "../rdcfes_amd/csrc/rdc_row.h"
 #include "../rdcfes_amd/csrc/rdc_tet4_fast.h"
 #include "../rdcfes_amd/csrc/rdc_tet4_pihna_moments.h"
+#include "../rdcfes_amd/csrc/rdc_tet4_ev.h"
 
 using namespace rdc;
 
@@ -105,8 +106,19 @@ int masks(const P* p, const double* u, const double* aux, double* worst) {
 }
 
 HostPrep g_prep;
+HostPrepEv g_ev;
+std::vector<uint32_t> g_conn;
 SolidGather g_gather;
 std::string g_err;
+
+// host emulation of one workgroup's LDS accumulation in k_tet4_ev
+struct EvHostSink {
+  double* M;
+  double* R;
+  int blk[4][4], nloc[4];
+  void mom(int m, int i, int j, double v) { M[m * ev::NBP + blk[i][j]] += v; }
+  void rhs(int a, int i, double v) { R[a * ev::MAXN + nloc[i]] += v; }
+};
 
 }  // namespace
 
@@ -159,7 +171,86 @@ int shim_masks(int model, const void* params, const double* u, const double* aux
 int shim_prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn, int nvar,
                     int64_t lds_budget, int block) {
   g_err = prep_build(nen, n_elem, n_node, n_owned, conn, nvar, (size_t)lds_budget, block, g_prep);
+  g_conn.assign(conn, conn + n_elem * nen);
   return g_err.empty() ? 0 : 1;
+}
+
+// element-visit lists (rdc_prep_ev.cpp) of the mesh of the last shim_prep_build; stats[6] = workgroups, visits, rows,
+// list stride, largest CSR image (doubles), owned nodes covered
+int shim_ev_build(int64_t lds_budget, int64_t* stats) {
+  g_err = prep_build_ev(g_prep, g_conn.data(), (size_t)lds_budget, g_ev);
+  if (!g_err.empty()) return 1;
+  int64_t covered = 0;
+  for (const auto& d : g_ev.desc) covered += d.nown;
+  stats[0] = (int64_t)g_ev.desc.size(); stats[1] = g_ev.n_visits; stats[2] = g_ev.n_rows; stats[3] = g_ev.nls;
+  stats[4] = (int64_t)g_ev.max_out_doubles; stats[5] = covered;
+  return 0;
+}
+
+// The kernel k_tet4_ev replayed on the host, phase by phase and workgroup by workgroup, from the SAME lists and the
+// SAME device functions (pihna_visit, pihna_expand): moments accumulated per cluster, expanded per node block into
+// the LDS image of the CSR segments, segments copied out.  val / rhs must be pre-filled by the caller (entries the
+// lists do not cover stay as they are, which the test detects).
+int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double* u, double* val, double* rhs) {
+  if (!g_ev.ok) return 1;
+  if (!PihnaNoCellTransport::applies(*p)) return 3;
+  const PihnaK k = Pihna::derive(*p);
+  const bool cube = exp_mode_of(k.ek) == 3;
+  const HostPrepEv& E = g_ev;
+  std::vector<double> M((size_t)ev::NM * ev::NBP), R(5 * ev::MAXN), img;
+  for (size_t w = 0; w < E.desc.size(); w++) {
+    const HostPrepEv::Desc& d = E.desc[w];
+    const HostPrepEv::Node* nt = &E.ntab[w * HostPrepEv::MAXN];
+    std::fill(M.begin(), M.end(), 0.0);
+    std::fill(R.begin(), R.end(), 0.0);
+    for (int x = 0; x < HostPrepEv::BLOCK; x++) {
+      const uint32_t pl = E.vloc[w * HostPrepEv::BLOCK + (size_t)x];
+      if (pl == 0xFFFFFFFFu) continue;
+      double X[4][3], U[4][5];
+      EvHostSink sink{M.data(), R.data(), {}, {}};
+      int li[4], r = 0;
+      for (int j = 0; j < 4; j++) {
+        li[j] = (int)((pl >> (8 * j)) & 0xFF);
+        if (li[j] >= (int)d.ntouch) return 4;
+        const uint32_t n = E.nlist[w * (size_t)E.nls + (size_t)li[j]];
+        for (int c = 0; c < 3; c++) X[j][c] = xyz[3 * (size_t)n + c];
+        for (int v = 0; v < 5; v++) U[j][v] = u[5 * (size_t)n + v];
+        r += li[j] < (int)d.nown;
+      }
+      for (int i = 0; i < 4; i++) {
+        sink.nloc[i] = i < r ? li[i] : 0;
+        const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 4 + (size_t)i];
+        for (int j = 0; j < 4; j++) {
+          sink.blk[i][j] = i < r ? (int)nt[li[i]].blk0 + (int)((word >> (8 * j)) & 0xFF) : 0;
+          if (i < r && sink.blk[i][j] >= (int)d.nb) return 5;
+        }
+      }
+      if (cube) ev::pihna_visit<3>(k, X, U, r, sink); else ev::pihna_visit<0>(k, X, U, r, sink);
+    }
+    img.assign(d.out_doubles, 0.0);
+    for (uint32_t t = 0; t < d.nb; t++) {
+      double e[ev::NM], o[25];
+      for (int m = 0; m < ev::NM; m++) e[m] = M[(size_t)m * ev::NBP + t];
+      ev::pihna_expand(k, e, o);
+      const uint32_t bt = E.btab[w * HostPrepEv::NBP + t];
+      const HostPrepEv::Node& nd = nt[bt & 0xFF];
+      const uint32_t s2 = bt >> 8;
+      if (s2 >= nd.len) return 6;
+      for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) {
+          const size_t at = (size_t)nd.obase + (size_t)a * 5 * nd.len + 5 * s2 + (size_t)b;
+          if (at >= img.size()) return 7;
+          img[at] = o[a * 5 + b];
+        }
+    }
+    for (uint32_t n = 0; n < d.nown; n++) {
+      const HostPrepEv::Node& nd = nt[n];
+      if (((25ull * nd.bptr) & 1) != (nd.obase & 1)) return 8;   // image and memory share the 16-byte phase
+      for (uint32_t x = 0; x < 25u * nd.len; x++) val[25 * (size_t)nd.bptr + x] = img[(size_t)nd.obase + x];
+      for (int a = 0; a < 5; a++) rhs[5 * (size_t)nd.node + a] = R[(size_t)a * ev::MAXN + n];
+    }
+  }
+  return 0;
 }
 const char* shim_prep_error() { return g_err.c_str(); }
 // gather lists of the two-pass solid assembly, from the last shim_prep_build

@@ -339,7 +339,7 @@ def test_two_rank_partitioned_assembly():
     assert all(err < TOL for _, err in res), res
 
 
-@pytest.mark.parametrize("opts", [{"slim": 1, "occupancy": 3}, {"slim": 1}, {"kernel": 3}, {"kernel": 4}, {"kernel": 2},
+@pytest.mark.parametrize("opts", [{"kernel": 7}, {"kernel": 7, "ev_occupancy": 2}, {"kernel": 5}, {"slim": 1, "occupancy": 3}, {"slim": 1}, {"kernel": 3}, {"kernel": 4}, {"kernel": 2},
                                   {"kernel": 1}, {"occupancy": 1}, {"xcd": 1}, {"prefetch": 16}, {"specialise": 0}, {"moments": 0},
                                   {"stagger": 8}, {"kernel": 6, "grid": 5}, {"kernel": 6, "grid": 5, "moments": 0}])
 def test_pihna_option_sets(oracle, opts):

@@ -1,0 +1,89 @@
+"""Element-visit / moment formulation of the shipped-pattern PIHNA TET4 assembly (rdc_tet4_ev.h, rdc_prep_ev.cpp) on
+the CPU: the kernel's phases replayed on the host from the same work lists and the same device functions
+(tests/host_shim.cpp::shim_ev_assemble) against the oracle's whole-mesh assembly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rdcfes_amd import pihna_params_from_dict, synth
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _ev(shim, conn, xyz, u, p, n_owned, budget=54000):
+    conn = np.ascontiguousarray(conn, dtype=np.uint32)
+    rc = shim.shim_prep_build(4, C.c_int64(conn.shape[0]), C.c_int64(xyz.shape[0]), C.c_int64(n_owned),
+                              conn.ctypes.data_as(C.POINTER(C.c_uint32)), 5, C.c_int64(60 * 1024), 256)
+    assert rc == 0, shim.shim_prep_error()
+    stats = (C.c_int64 * 6)()
+    rc = shim.shim_ev_build(C.c_int64(budget), stats)
+    assert rc == 0, shim.shim_prep_error()
+    n_wg, n_vis, n_rows, nls, max_out, covered = list(stats)
+    assert covered == n_owned                      # every owned node is in exactly one cluster
+    bptr = np.empty(shim.shim_prep_size(0), dtype=np.int64)
+    shim.shim_prep_copy(0, bptr.ctypes.data_as(C.c_void_p))
+    val = np.full(25 * bptr[n_owned], np.nan)
+    rhs = np.full(5 * n_owned, np.nan)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    rc = shim.shim_ev_assemble(C.byref(p), dp(xyz), dp(u), dp(val), dp(rhs))
+    assert rc == 0, rc
+    return val, rhs, dict(n_wg=n_wg, n_vis=n_vis, n_rows=n_rows, nls=nls, max_out=max_out)
+
+
+@pytest.mark.parametrize("order", ["lex", "random"])
+@pytest.mark.parametrize("pvariant", ["shipped", "shipped_realexp"])
+def test_ev_replay_matches_oracle(oracle, shim, order, pvariant):
+    conn, xyz = synth.kuhn_tet_mesh(7, order=order)
+    u = synth.pihna_fields(xyz)
+    d = synth.pihna_param_dict("shipped")
+    if pvariant == "shipped_realexp":
+        d["cells_max_capacity/exponent"] = 2.5
+    p = pihna_params_from_dict(d)
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    val, rhs, st = _ev(shim, conn, xyz, u, p, xyz.shape[0])
+    assert np.isfinite(val).all() and np.isfinite(rhs).all()      # every CSR value and rhs entry is produced
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
+    # an element is visited by every cluster that owns one of its nodes; a visit serves 1..4 rows
+    assert st["n_rows"] == 4 * conn.shape[0]
+    assert conn.shape[0] <= st["n_vis"] <= st["n_rows"]
+    if order == "lex":
+        assert st["n_rows"] / st["n_vis"] > 1.5
+
+
+def test_ev_replay_on_a_ghosted_partition(oracle, shim):
+    conn, xyz = synth.kuhn_tet_mesh(6, order="random")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    n_owned = int(0.6 * xyz.shape[0])
+    conn = conn[(conn < n_owned).any(axis=1)]
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u, n_owned=n_owned)
+    val, rhs, st = _ev(shim, conn, xyz, u, p, n_owned)
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
+    assert st["n_rows"] == int((conn < n_owned).sum())
+
+
+def test_ev_replay_clamped_branches(oracle, shim):
+    """saturated / empty crowding, vascular fraction at 0 and 1, sub-threshold vasculature, all-zero nodes (0/0 -> NaN in the
+    same entries as the oracle): the states of test_gpu_parity.py::test_pihna_shipped_pattern_branches"""
+    conn, xyz = synth.kuhn_tet_mesh(6, order="random")
+    rng = np.random.default_rng(5)
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    x = xyz[:, 0]
+    u[x < 0.25, :4] *= 60.0
+    m = (x >= 0.25) & (x < 0.4)
+    u[m, 3] = rng.uniform(0.0, 2.0 * p.cells_min_capacity, int(m.sum()))
+    u[(x >= 0.4) & (x < 0.5), 1:3] = 0.0
+    u[(x >= 0.5) & (x < 0.6), 3] = 0.0
+    u[x > 0.7] = 0.0
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    val, rhs, _ = _ev(shim, conn, xyz, u, p, xyz.shape[0])
+    assert np.isnan(val0).any()
+    assert np.array_equal(np.isnan(val), np.isnan(val0)) and np.array_equal(np.isnan(rhs), np.isnan(rhs0))
+    ok, okr = ~np.isnan(val0), ~np.isnan(rhs0)
+    assert rel(val[ok], val0[ok]) < 1e-10 and rel(rhs[okr], rhs0[okr]) < 1e-10
