@@ -41,7 +41,6 @@ struct EvDev {
   const uint32_t* vloc = nullptr;
   const uint32_t* vslot = nullptr;
   const HostPrepEv::Node* ntab = nullptr;
-  const uint16_t* btab = nullptr;
   const uint32_t* wg_perm = nullptr;   // two-part assembly: workgroup order with the interior clusters first (else null)
   int wg_begin = 0, wg_count = -1;
   int nls = 0;

@@ -111,7 +111,7 @@ struct HostPrepEv {
   };
   struct Node {            // 16 bytes per owned node of a workgroup
     uint32_t bptr;         // first node block of the node's rows (CSR value offset = nvar^2 * bptr)
-    uint16_t len, blk0;    // node blocks in the row; first block of the node inside the workgroup's moment slice
+    uint16_t len, blk0;    // node blocks in the row (<= 16); index a of the node in the cluster: block (a, slot s) of the moment slice = s * 16 + a
     uint32_t obase;        // offset of the node's CSR segment inside the LDS image (same 16-byte phase as in memory)
     uint32_t node;         // node id
   };
@@ -123,9 +123,10 @@ struct HostPrepEv {
   std::vector<uint32_t> vloc;        // [n_wg][256] four 8-bit list positions of the visit's vertices, owned first; ~0u = none
   std::vector<uint32_t> vslot;       // [n_wg][256][4]: byte j of word i = column slot of vertex j in the row of vertex i
   std::vector<Node> ntab;            // [n_wg][16]
-  std::vector<uint16_t> btab;        // [n_wg][256] node block -> owner (low byte: owned-node index, high byte: slot in its row)
   // statistics: element visits and (row, visit) pairs over all workgroups
   int64_t n_visits = 0, n_rows = 0;
+  int64_t n_conflicts = 0;           // rows whose node already sits at the same vertex position of their 16-lane group
+  int64_t n_group_rows = 0;          // sum over 16-lane groups of the rows they emit (LDS passes per accumulated value)
 };
 // needs P.bptr / P.bcol / P.eslot of prep_build; lds_budget = LDS bytes a workgroup may use (3 workgroups per CU: 53 KB)
 std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& out);

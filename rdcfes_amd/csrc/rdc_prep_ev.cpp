@@ -4,7 +4,17 @@
 // owned node that shares the most elements with the cluster joins it, until a limit is hit (16 nodes, 256 element
 // visits, 255 distinct nodes, 256 node blocks, the LDS budget of the CSR image).  The more elements a cluster holds
 // completely, the more rows an element visit serves (the per-element work is done once per visit).
+//
+// LDS layout and schedule.  gfx950 executes a ds_add_f64 wave instruction as 4 groups of 16 lanes; inside a group, lanes
+// whose double index is equal modulo 16 are serialised (tools/lds_bank_model.hip), and so are lanes that hit the same
+// address.  The moment slice is therefore laid out [moment][slot in the row][owned node]: block (node a, slot s) has
+// index s * 16 + a, i.e. its bank is the ROW NODE's index a.  One instruction of the kernel adds moment m of block
+// (vertex i, vertex j) for all lanes, so it is free of bank and address conflicts iff, inside every 16-lane group, the
+// lanes that execute it have DIFFERENT row nodes at vertex position i.  The vertex order inside the owned set is free,
+// and so is the lane of a visit inside its wave: the schedule below places every visit in the 16-lane group and with
+// the vertex order that collide least (ideally: every owned node appears at most once per group and position).
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 
@@ -139,8 +149,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
   E.vloc.assign((size_t)nwg * BLOCK, 0xFFFFFFFFu);
   E.vslot.assign((size_t)nwg * BLOCK * 4, 0);
   E.ntab.assign((size_t)nwg * MAXN, HostPrepEv::Node{0, 0, 0, 0, 0});
-  E.btab.assign((size_t)nwg * NBP, 0);
-  std::vector<int64_t> rows_w((size_t)nwg, 0);
+  std::vector<int64_t> rows_w((size_t)nwg, 0), conf_w((size_t)nwg, 0), pass_w((size_t)nwg, 0);
   std::vector<size_t> img_w((size_t)nwg, 0);
 #pragma omp parallel for schedule(dynamic, 256)
   for (int64_t w = 0; w < nwg; w++) {
@@ -159,62 +168,135 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       const uint32_t n = cl[x];
       HostPrepEv::Node& nd = E.ntab[(size_t)w * MAXN + x];
       const int64_t len = P.bptr[n + 1] - P.bptr[n];
-      nd.bptr = (uint32_t)P.bptr[n]; nd.len = (uint16_t)len; nd.blk0 = (uint16_t)blk; nd.node = n;
+      nd.bptr = (uint32_t)P.bptr[n]; nd.len = (uint16_t)len; nd.blk0 = (uint16_t)x; nd.node = n;   // block (x, slot s) lives at s * MAXN + x
       const uint32_t phase = (uint32_t)((25 * P.bptr[n]) & 1);
       if ((ob & 1) != phase) ob++;          // the image of a segment starts at the 16-byte phase it has in memory
       nd.obase = ob;
       ob += (uint32_t)(25 * len);
-      for (int64_t s2 = 0; s2 < len; s2++) E.btab[(size_t)w * NBP + blk + (uint32_t)s2] = (uint16_t)(x | ((uint32_t)s2 << 8));
       blk += (uint32_t)len;
-      if (len > 255) fail = 1;
+      if (len > NBP / MAXN) fail = 1;
     }
     d.nb = blk;
     d.out_doubles = (ob + 1) & ~1u;
     img_w[(size_t)w] = d.out_doubles;
-    if (blk > (uint32_t)NBP) fail = 1;
     // visits: vertices permuted owned-first; sorted by the number of owned vertices (descending) so that the waves of
-    // the kernel are (nearly) uniform in the number of rows they emit
-    struct V { uint32_t e; int r; int perm[4]; };
+    // the kernel are (nearly) uniform in the number of rows they emit; inside a wave, conflict-aware placement (above)
+    struct V { uint32_t e; int r; int own[4]; int rest[4]; };
     std::vector<V> vv(vis.size());
     for (size_t x = 0; x < vis.size(); x++) {
       V& v = vv[x];
       v.e = vis[x];
-      int own[4], rest[4], no = 0, nr = 0;
+      int no = 0, nr = 0;
       for (int j = 0; j < 4; j++) {
         const uint32_t m = conn[(int64_t)v.e * 4 + j];
-        if ((int64_t)m < n_owned && cluster_of[m] == (int32_t)w) own[no++] = j; else rest[nr++] = j;
+        if ((int64_t)m < n_owned && cluster_of[m] == (int32_t)w) v.own[no++] = j; else v.rest[nr++] = j;
       }
       v.r = no;
-      for (int j = 0; j < no; j++) v.perm[j] = own[j];
-      for (int j = 0; j < nr; j++) v.perm[no + j] = rest[j];
     }
     std::stable_sort(vv.begin(), vv.end(), [](const V& a, const V& b) { return a.r > b.r; });
+    // owned-node index (position in cl) of a local vertex
+    auto own_index = [&](const V& v, int j) {
+      const uint32_t m = conn[(int64_t)v.e * 4 + j];
+      return (int)(std::find(cl.begin(), cl.end(), m) - cl.begin());
+    };
+    // inside a class of equal r: deal the visits round-robin over their owned nodes, so that the 64 visits a wave gets
+    // spread evenly over the cluster's nodes (a node's elements are neighbours in element order)
+    for (size_t b = 0; b < vv.size();) {
+      size_t e2 = b;
+      while (e2 < vv.size() && vv[e2].r == vv[b].r) e2++;
+      std::vector<std::vector<V>> bucket((size_t)MAXN);
+      std::vector<int> load((size_t)MAXN, 0);
+      for (size_t x = b; x < e2; x++) {      // bucket = the owned node of the visit that has the fewest visits so far
+        int bestn = -1;
+        for (int i = 0; i < vv[x].r; i++) {
+          const int oi = own_index(vv[x], vv[x].own[i]);
+          if (bestn < 0 || load[(size_t)oi] < load[(size_t)bestn]) bestn = oi;
+        }
+        if (bestn < 0) bestn = 0;
+        load[(size_t)bestn]++;
+        bucket[(size_t)bestn].push_back(vv[x]);
+      }
+      size_t out = b;
+      for (size_t round = 0; out < e2; round++)
+        for (int n = 0; n < MAXN; n++)
+          if (round < bucket[(size_t)n].size()) vv[out++] = bucket[(size_t)n][round];
+      b = e2;
+    }
+    static const int PERM4[24][4] = {{0,1,2,3},{0,1,3,2},{0,2,1,3},{0,2,3,1},{0,3,1,2},{0,3,2,1},{1,0,2,3},{1,0,3,2},{1,2,0,3},{1,2,3,0},{1,3,0,2},{1,3,2,0},
+                                     {2,0,1,3},{2,0,3,1},{2,1,0,3},{2,1,3,0},{2,3,0,1},{2,3,1,0},{3,0,1,2},{3,0,2,1},{3,1,0,2},{3,1,2,0},{3,2,0,1},{3,2,1,0}};
+    const int nperm[5] = {1, 1, 2, 6, 24};
+    // the 2 / 6 permutations of 2 / 3 items are the PERM4 entries that keep the tail fixed
+    auto perm_of = [&](int r2, int q, int* out) {
+      int cnt = 0;
+      for (int x = 0; x < 24; x++) {
+        bool ok = true;
+        for (int y = r2; y < 4; y++) ok = ok && PERM4[x][y] == y;
+        if (!ok) continue;
+        if (cnt == q) { for (int y = 0; y < 4; y++) out[y] = PERM4[x][y]; return; }
+        cnt++;
+      }
+    };
+    // Placement.  An atomic instruction of the kernel costs one LDS pass per 16-lane group that has an active lane, plus
+    // the serialisation of lanes with the same row node (same bank; same ADDRESS for the diagonal block, ~6 cycles per
+    // extra lane).  Visits are taken in descending r (node-interleaved inside a class) and each goes to the group and
+    // vertex order that (1) adds no node twice at a vertex position of the group, (2) does not raise the number of rows
+    // the group emits, (3) fills the fullest such group -- groups end up sorted by r and dense.
+    std::vector<std::array<uint16_t, 4>> used(16);           // [group][vertex position]: owned nodes already there
+    for (auto& u2 : used) u2.fill(0);
+    std::vector<int> fill_g(16, 0), maxr_g(16, 0);
     for (size_t x = 0; x < vv.size(); x++) {
       const V& v = vv[x];
+      int oi[4] = {0, 0, 0, 0};
+      for (int i = 0; i < v.r; i++) oi[i] = own_index(v, v.own[i]);
+      int best_g = -1, best_q = 0;
+      long best_cost = 1L << 60;
+      for (int g = 0; g < 16; g++) {
+        if (fill_g[g] >= 16) continue;
+        const long grow = fill_g[g] == 0 ? 4 * v.r : (v.r > maxr_g[g] ? 100 * (v.r - maxr_g[g]) : 0);   // rows the group starts to emit
+        for (int q = 0; q < nperm[v.r]; q++) {
+          int pm[4];
+          perm_of(v.r, q, pm);
+          long cost = grow + (16 - fill_g[g]);
+          for (int i = 0; i < v.r; i++) cost += ((used[(size_t)g][(size_t)i] >> oi[pm[i]]) & 1) ? 1000 : 0;
+          if (cost < best_cost) { best_cost = cost; best_g = g; best_q = q; }
+        }
+      }
+      if (best_g < 0) { fail = 1; break; }
+      conf_w[(size_t)w] += best_cost / 1000;   // rows whose node already sits at the same vertex position of their 16-lane group
+      int pm[4];
+      perm_of(v.r, best_q, pm);
+      int perm[4];
+      for (int i = 0; i < v.r; i++) { perm[i] = v.own[pm[i]]; used[(size_t)best_g][(size_t)i] |= (uint16_t)(1u << oi[pm[i]]); }
+      for (int j = v.r; j < 4; j++) perm[j] = v.rest[j - v.r];
+      maxr_g[best_g] = std::max(maxr_g[best_g], v.r);
+      const size_t lane = (size_t)best_g * 16 + (size_t)fill_g[best_g]++;
       uint32_t packed = 0;
       uint32_t li[4];
       for (int j = 0; j < 4; j++) {
-        const uint32_t m = conn[(int64_t)v.e * 4 + v.perm[j]];
+        const uint32_t m = conn[(int64_t)v.e * 4 + perm[j]];
         const uint32_t pos = (uint32_t)(std::find(t.begin(), t.end(), m) - t.begin());
         li[j] = pos;
         packed |= pos << (8 * j);
       }
-      E.vloc[(size_t)w * BLOCK + x] = packed;
+      E.vloc[(size_t)w * BLOCK + lane] = packed;
       rows_w[(size_t)w] += v.r;
       for (int i = 0; i < v.r; i++) {
         uint32_t word = 0;
         for (int j = 0; j < 4; j++)
-          word |= (uint32_t)P.eslot[(size_t)v.e * 16 + (size_t)v.perm[i] * 4 + (size_t)v.perm[j]] << (8 * j);
-        E.vslot[((size_t)w * BLOCK + x) * 4 + (size_t)i] = word;
+          word |= (uint32_t)P.eslot[(size_t)v.e * 16 + (size_t)perm[i] * 4 + (size_t)perm[j]] << (8 * j);
+        E.vslot[((size_t)w * BLOCK + lane) * 4 + (size_t)i] = word;
         if (li[i] >= cl.size()) fail = 1;
       }
     }
+    for (int g = 0; g < 16; g++) pass_w[(size_t)w] += maxr_g[g];
   }
   if (fail) return "internal: element-visit list construction failed";
   for (int64_t w = 0; w < nwg; w++) {
     E.max_out_doubles = std::max(E.max_out_doubles, img_w[(size_t)w]);
     E.n_visits += (int64_t)E.desc[(size_t)w].nvis;
     E.n_rows += rows_w[(size_t)w];
+    E.n_conflicts += conf_w[(size_t)w];
+    E.n_group_rows += pass_w[(size_t)w];
   }
   E.ok = true;
   return std::string();

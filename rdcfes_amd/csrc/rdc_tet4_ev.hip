@@ -18,28 +18,34 @@ template <class M> struct RecEv {
   static constexpr int N = (RAW + 1) & ~1;
 };
 
+// ABL (diagnostic builds, results WRONG): 1 = plain LDS stores instead of atomics, 2 = no LDS accumulation traffic
+template <int ABL>
 struct EvSink {
   double* p[4][4];   // LDS address of moment 0 of block (node i, node j)
   double* pr[4];     // LDS address of rhs entry 0 of node i
+  double sum = 0.0;
   __device__ __forceinline__ void mom(int m, int i, int j, double v) {
-    __hip_atomic_fetch_add(p[i][j] + m * ev::NBP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ABL == 0) __hip_atomic_fetch_add(p[i][j] + m * ev::NBP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (ABL == 1) p[i][j][m * ev::NBP] = v;
+    else sum += v;
   }
   __device__ __forceinline__ void rhs(int a, int i, double v) {
-    __hip_atomic_fetch_add(pr[i] + a * ev::MAXN, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ABL == 0) __hip_atomic_fetch_add(pr[i] + a * ev::MAXN, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (ABL == 1) pr[i][a * ev::MAXN] = v;
+    else sum += v;
   }
 };
 
-template <int EXP_MODE, int MINW>
+template <int EXP_MODE, int MINW, int ABL = 0>
 __global__ void __launch_bounds__(256, MINW)
 k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
-          const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint16_t* __restrict__ btab,
+          const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab,
           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
           double* __restrict__ rhs, const int nls, const int wg_begin) {
   constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
   constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP | R: 5 x MAXN | records: NP x nls x 16 B]
   __shared__ HostPrepEv::Node snode[MAXN];
-  __shared__ uint16_t sbt[NBP];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   int w = (int)blockIdx.x + wg_begin;
@@ -59,7 +65,6 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   const uint4 sl = reinterpret_cast<const uint4*>(vslot)[(size_t)w * BLOCK + tid];
   const HostPrepEv::Desc d = desc[w];
   if (tid < MAXN) snode[tid] = ntab[(size_t)w * MAXN + tid];
-  sbt[tid] = btab[(size_t)w * NBP + tid];
   if (wv < rounds) {
     const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
 #pragma unroll
@@ -88,22 +93,23 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
     const int nown = (int)d.nown;
     // the owned vertices come first: r = number of list positions below nown
     const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
-    EvSink sink;
+    EvSink<ABL> sink;
     const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int b0 = (i < r) ? (int)snode[i < r ? li[i] : 0].blk0 : 0;
-      sink.pr[i] = R + ((i < r) ? li[i] : 0);
+      const int a = (i < r) ? li[i] : 0;   // owned vertices come first in the node list: list position == cluster index
+      sink.pr[i] = R + a;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + b0 + (int)((sw[i] >> (8 * j)) & 0xFF);
+      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (8 * j)) & 0xFF);   // block (a, slot): slot * 16 + a
     }
-    ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
+    if (ABL < 3) ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);   // ABL 3: no compute phase at all (data movement only)
+    if (ABL == 2 && sink.sum == 1.2345e300) rhs[0] = sink.sum;  // keeps the arithmetic alive
   }
   __syncthreads();
-  // phase 2: node block tid: moments -> entries
-  const int nb = (int)d.nb;
+  // phase 2: node block tid = slot * 16 + node: moments -> entries
   double e[NM];
-  const bool has = tid < nb;
+  const int bn = tid & (MAXN - 1), bs = tid >> 4;
+  const bool has = bn < (int)d.nown && bs < (int)snode[bn < (int)d.nown ? bn : 0].len;
   if (has) {
 #pragma unroll
     for (int m = 0; m < NM; m++) e[m] = lds[m * NBP + tid];
@@ -116,8 +122,7 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   if (has) {
     double o[25];
     ev::pihna_expand(k, e, o);
-    const uint32_t bt = sbt[tid];
-    const int n = (int)(bt & 0xFF), s = (int)(bt >> 8);
+    const int n = bn, s = bs;
     const int len5 = 5 * (int)snode[n].len;
     double* dst = lds + snode[n].obase + 5 * s;
 #pragma unroll
@@ -156,7 +161,15 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t lds_bytes = lds_doubles * sizeof(double);
 #define RDC_EV(MODE, MINW)                                                                                          \
   hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.btab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+                     E.vslot, E.ntab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+  if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 3) {   // diagnostic builds (timing only)
+#define RDC_EVA(X)                                                                                                    \
+  hipLaunchKernelGGL((k_tet4_ev<3, 3, X>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
+                     E.vslot, E.ntab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+    if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else RDC_EVA(3);
+#undef RDC_EVA
+    return hipGetLastError();
+  }
   if (a.exp_mode == 3) { if (a.opt_ev_occ == 2) RDC_EV(3, 2); else RDC_EV(3, 3); }
   else { if (a.opt_ev_occ == 2) RDC_EV(0, 2); else RDC_EV(0, 3); }
 #undef RDC_EV

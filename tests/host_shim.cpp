@@ -221,21 +221,21 @@ int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double*
         sink.nloc[i] = i < r ? li[i] : 0;
         const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 4 + (size_t)i];
         for (int j = 0; j < 4; j++) {
-          sink.blk[i][j] = i < r ? (int)nt[li[i]].blk0 + (int)((word >> (8 * j)) & 0xFF) : 0;
-          if (i < r && sink.blk[i][j] >= (int)d.nb) return 5;
+          const int slot = (int)((word >> (8 * j)) & 0xFF);
+          sink.blk[i][j] = i < r ? slot * ev::MAXN + li[i] : 0;     // block (node a, slot s) of the slice: s * 16 + a
+          if (i < r && slot >= (int)nt[li[i]].len) return 5;
         }
       }
       if (cube) ev::pihna_visit<3>(k, X, U, r, sink); else ev::pihna_visit<0>(k, X, U, r, sink);
     }
     img.assign(d.out_doubles, 0.0);
-    for (uint32_t t = 0; t < d.nb; t++) {
+    for (uint32_t t = 0; t < (uint32_t)ev::NBP; t++) {
+      const uint32_t bn = t & (ev::MAXN - 1), s2 = t >> 4;
+      if (bn >= d.nown || s2 >= nt[bn].len) continue;
       double e[ev::NM], o[25];
       for (int m = 0; m < ev::NM; m++) e[m] = M[(size_t)m * ev::NBP + t];
       ev::pihna_expand(k, e, o);
-      const uint32_t bt = E.btab[w * HostPrepEv::NBP + t];
-      const HostPrepEv::Node& nd = nt[bt & 0xFF];
-      const uint32_t s2 = bt >> 8;
-      if (s2 >= nd.len) return 6;
+      const HostPrepEv::Node& nd = nt[bn];
       for (int a = 0; a < 5; a++)
         for (int b = 0; b < 5; b++) {
           const size_t at = (size_t)nd.obase + (size_t)a * 5 * nd.len + 5 * s2 + (size_t)b;
