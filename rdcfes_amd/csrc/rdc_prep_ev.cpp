@@ -47,8 +47,39 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
     std::vector<uint32_t> emark((size_t)n_elem, 0), nmark((size_t)n_node, 0), gain((size_t)n_owned, 0), gstamp((size_t)n_owned, 0);
     uint32_t stamp = 0;
     std::vector<uint32_t> cand, tmp, rejected;
-    for (int64_t seed = 0; seed < n_owned; seed++) {
-      if (cluster_of[seed] >= 0) continue;
+    // Seeds: always the unassigned node with the FEWEST unassigned neighbours (lowest id among equals).  Clusters then
+    // grow along the front of what is already assigned and pick up nodes before they are cut off; taking the seeds in
+    // id order instead leaves ~5% one-node clusters behind on a Kuhn mesh, each costing a whole workgroup.
+    // free_nb[n] = unassigned owned neighbours of n (node graph = the block pattern); lazy bucket queue on it.
+    std::vector<int32_t> free_nb((size_t)n_owned, 0);
+    int max_nb = 0;
+    for (int64_t n = 0; n < n_owned; n++) {
+      int c = 0;
+      for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) c += (P.bcol[b] != (int32_t)n && (int64_t)P.bcol[b] < n_owned);
+      free_nb[n] = c;
+      max_nb = std::max(max_nb, c);
+    }
+    std::vector<std::vector<uint32_t>> bucket((size_t)max_nb + 1);
+    for (int64_t n = n_owned - 1; n >= 0; n--) bucket[(size_t)free_nb[n]].push_back((uint32_t)n);   // popped from the back: lowest id first
+    auto assigned_update = [&](uint32_t n) {     // n has just been assigned: its neighbours lose a free neighbour
+      for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) {
+        const int32_t m = P.bcol[b];
+        if (m == (int32_t)n || (int64_t)m >= n_owned || cluster_of[m] >= 0) continue;
+        free_nb[m]--;
+        bucket[(size_t)free_nb[m]].push_back((uint32_t)m);   // lazy: stale entries in higher buckets are skipped when popped
+      }
+    };
+    int64_t n_assigned = 0;
+    while (n_assigned < n_owned) {
+      int64_t seed = -1;
+      for (size_t k = 0; k < bucket.size() && seed < 0; k++) {
+        while (!bucket[k].empty()) {
+          const uint32_t n = bucket[k].back();
+          bucket[k].pop_back();
+          if (cluster_of[n] < 0 && free_nb[n] == (int32_t)k) { seed = n; break; }
+        }
+      }
+      if (seed < 0) return "internal: seed queue ran dry";
       stamp++;
       std::vector<uint32_t> cl;
       int64_t nvis = 0, ntouch = 0, nb = 0;
@@ -71,6 +102,8 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       auto add = [&](uint32_t n) {
         cluster_of[n] = (int32_t)clusters.size();
         cl.push_back(n);
+        n_assigned++;
+        assigned_update(n);
         nb += P.bptr[n + 1] - P.bptr[n];
         img += (size_t)25 * (size_t)(P.bptr[n + 1] - P.bptr[n]) + 1;
         for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
@@ -95,7 +128,10 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
         for (size_t x = 0; x < cand.size(); x++) {
           const uint32_t c = cand[x];
           if (cluster_of[c] != -1) continue;
-          if (best < 0 || gain[c] > gain[cand[(size_t)best]] || (gain[c] == gain[cand[(size_t)best]] && c < cand[(size_t)best])) best = (int)x;
+          if (best < 0) { best = (int)x; continue; }
+          const uint32_t bc = cand[(size_t)best];
+          // most shared elements; then the node with the fewest unassigned neighbours (it would be cut off otherwise)
+          if (gain[c] > gain[bc] || (gain[c] == gain[bc] && (free_nb[c] < free_nb[bc] || (free_nb[c] == free_nb[bc] && c < bc)))) best = (int)x;
         }
         if (best < 0) break;
         const uint32_t c = cand[(size_t)best];
