@@ -284,6 +284,8 @@ def main():
 
     ctx = AssemblyContext(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # same stream as the halo's torch ops
+    if lp is not None and a.overlap and lp.n_interior > 0:
+        ctx.set_option("interior_nodes", int(lp.n_interior))   # before the upload: the work lists respect the split
     ctx.mesh_upload(4, l_conn, l_xyz, 5, n_owned=n_owned)
     ctx.set_scatter({"auto": 0, "coloured": 1, "rowgather": 2}[a.scatter])
     ctx.set_kernel_variant({"auto": 0, "generic": 1}[a.variant])

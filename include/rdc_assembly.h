@@ -196,7 +196,8 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * "solid_kernel", "solid_gather", "solid_split", "solid_store" select alternative / diagnostic kernels.
  * Two-part assembly, for overlapping a halo exchange with the assembly of rows that do not need it:
  * "interior_nodes" = n states that no element of the owned nodes [0, n) contains a ghost node (the caller numbers
- * its owned nodes interior-first); with "part" = 1 an assemble call then writes only the rows of leading workgroups
+ * its owned nodes interior-first; set it BEFORE rdc_mesh_upload where possible: the work lists are then built so that
+ * part 1 covers every interior row, otherwise only the workgroups that happen to lie inside [0, n)); with "part" = 1 an assemble call then writes only the rows of leading workgroups
  * inside [0, n), with "part" = 2 the remaining rows, with "part" = 0 (default) all rows.  Part 1 followed by part 2
  * gives exactly the matrix and residual of one whole call.  Paths that cannot launch sub-ranges (HEX8, the
  * coloured strategy, the solid system) write nothing in part 1 and everything in part 2.

@@ -42,6 +42,7 @@ CXXFLAGS = [
 ]
 # experiments only: extra compiler flags for every HIP source, e.g. RDC_EXTRA_HIPCC_FLAGS="-mllvm -amdgpu-enable-max-ilp-scheduling-strategy=1"
 CXXFLAGS += os.environ.get("RDC_EXTRA_HIPCC_FLAGS", "").split()
+RESOURCES = LIBDIR / "kernel_resources.json"   # per kernel: registers, scratch, occupancy (from -Rpass-analysis)
 
 
 def hipcc() -> str:
@@ -67,16 +68,38 @@ def _newest_dep() -> float:
     return max(p.stat().st_mtime for p in deps)
 
 
-def _compile(src: str, extra=()) -> Path:
+def _parse_resources(stderr: str) -> dict:
+    """kernel-resource-usage remarks of one translation unit -> {mangled kernel name: {vgprs, agprs, scratch, ...}}"""
+    import re
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+            "Occupancy [waves/SIMD]": "waves_per_simd", "VGPRs Spill": "vgpr_spills", "SGPRs Spill": "sgpr_spills",
+            "LDS Size [bytes/block]": "static_lds_bytes"}
+    for ln in stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", ln)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", ln)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def _compile(src: str, extra=()):
     OBJ.mkdir(exist_ok=True)
     obj = OBJ / (src.rsplit(".", 1)[0] + ".o")
-    cmd = [hipcc(), *CXXFLAGS, *extra, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+    hip = src.endswith(".hip")
+    cmd = [hipcc(), *CXXFLAGS, *extra, *(["-Rpass-analysis=kernel-resource-usage"] if hip else []), "-x", "hip", "-c",
+           str(CSRC / src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
-    return obj
+    res = _parse_resources(r.stderr) if hip else {}
+    rest = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln and not ln.lstrip().startswith(("|", "^")) and "__launch_bounds__" not in ln)
+    if rest.strip() and os.environ.get("RDC_BUILD_VERBOSE"):
+        sys.stderr.write(rest + "\n")
+    return obj, res
 
 
 def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
@@ -87,11 +110,17 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
     if verbose:
         print(f"[rdcfes_amd.build] compiling {len(srcs)} sources for {ARCH} ...", flush=True)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(_compile, srcs))
+        done = list(ex.map(_compile, srcs))
+    objs = [d[0] for d in done]
+    resources = {}
+    for _, res in done:
+        resources.update(res)
     cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fopenmp", "-o", str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    import json
+    RESOURCES.write_text(json.dumps(resources, indent=0, sort_keys=True))
     if verbose:
         print(f"[rdcfes_amd.build] built {LIB}", flush=True)
     return LIB

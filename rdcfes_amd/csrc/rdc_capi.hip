@@ -596,7 +596,8 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   c->ev_perm_interior = -2;
   if (elem_type == RDC_TET4 && nvar == 5 && P.rg2_ok) {
     // element-visit lists of the PIHNA kernel; a mesh they cannot describe simply keeps the pair kernels
-    const std::string ev_err = prep_build_ev(P, conn, (size_t)c->opt_ev_lds, c->prep_ev);
+    // "interior_nodes" set BEFORE the upload lets the clusters respect the interior / near-ghost split (two-part assembly)
+    const std::string ev_err = prep_build_ev(P, conn, (size_t)c->opt_ev_lds, c->prep_ev, c->opt_interior <= n_owned ? c->opt_interior : -1);
     if (ev_err.empty()) {
       if ((rc = dev_upload(c, c->ev_desc, c->prep_ev.desc))) return rc;
       if ((rc = dev_upload(c, c->ev_nlist, c->prep_ev.nlist))) return rc;

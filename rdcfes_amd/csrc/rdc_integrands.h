@@ -75,7 +75,9 @@ RDC_HD double rcp(double x) {
 // pow() kept out of line on the device: inlined into the generic row-gather kernel of a 5-unknown model (256 VGPRs
 // + AGPR spills) the device-library pow produced NaN for positive arguments (observed with Proteas on TET4,
 // ROCm 7.2); as a call it is correct everywhere, and the general-exponent path is the rare one.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RDC_POW_INLINE)   // diagnostic builds only (tools/pow_inline_probe.sh)
+__device__ __forceinline__ static double rdc_pow(double x, double e) { return pow(x, e); }
+#elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __attribute__((noinline)) static double rdc_pow(double x, double e) { return pow(x, e); }
 #else
 static inline double rdc_pow(double x, double e) { return pow(x, e); }

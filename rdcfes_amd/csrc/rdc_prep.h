@@ -129,7 +129,8 @@ struct HostPrepEv {
   int64_t n_group_rows = 0;          // sum over 16-lane groups of the rows they emit (LDS passes per accumulated value)
 };
 // needs P.bptr / P.bcol / P.eslot of prep_build; lds_budget = LDS bytes a workgroup may use (3 workgroups per CU: 53 KB)
-std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& out);
+// n_interior >= 0: owned nodes [0, n_interior) are "interior" (two-part assembly): clusters do not mix the two kinds
+std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& out, int64_t n_interior = -1);
 
 // returns empty string on success, else an error message
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,

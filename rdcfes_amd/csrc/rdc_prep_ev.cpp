@@ -22,7 +22,7 @@
 
 namespace rdc {
 
-std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& E) {
+std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& E, int64_t n_interior) {
   E = HostPrepEv();
   if (P.nen != 4 || P.nvar != 5) return "element-visit lists exist for TET4 with 5 unknowns only";
   const int64_t n_elem = P.n_elem, n_node = P.n_node, n_owned = P.n_owned;
@@ -114,7 +114,9 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
           for (int j = 0; j < 4; j++) {
             const uint32_t m = conn[(int64_t)e * 4 + j];
             if (nmark[m] != stamp) { nmark[m] = stamp; ntouch++; }
-            if ((int64_t)m < n_owned && cluster_of[m] == -1) {
+            // two-part assembly: a cluster never mixes interior nodes (rows assembled before the halo exchange has
+            // landed) with the others, so the interior rows stay complete clusters
+            if ((int64_t)m < n_owned && cluster_of[m] == -1 && (n_interior < 0 || (((int64_t)m < n_interior) == (seed < n_interior)))) {
               if (gstamp[m] != stamp) { gstamp[m] = stamp; gain[m] = 0; cand.push_back(m); }
               gain[m]++;
             }

@@ -368,6 +368,7 @@ def test_two_part_assembly_equals_whole(frac):
     p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
     n_int = int(frac * xyz.shape[0])
     with AssemblyContext(0) as ctx:
+        ctx.set_option("interior_nodes", n_int)            # known before the upload: the work lists respect the split
         ctx.mesh_upload(4, conn, xyz, 5)
         ctx.field_upload(FIELD_OLD_SOLUTION, u)
         ctx.assemble_pihna(p)
