@@ -121,3 +121,33 @@ def test_halo_exchange_gloo(world):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert all(b > 0 for _, _, b in res)
+
+
+def test_eight_way_partition_of_k20_plan_and_exchange():
+    """The shape of the 8-GPU run (BASELINE cfg4) at small size: 8-way RCB of K(20), plan symmetry over all 28 rank pairs,
+    and the grouped exchange itself on an 8-rank gloo group."""
+    conn, xyz = synth.kuhn_tet_mesh(20, order="lex")
+    part = partition.partition_rcb(xyz[conn].mean(axis=1), 8)
+    owner = partition.node_owners(conn, part, xyz.shape[0], 8)
+    lps = [partition.build_local(conn, xyz, part, r, 8, owner=owner) for r in range(8)]
+    assert sum(lp.n_owned for lp in lps) == xyz.shape[0]
+    assert sum(lp.n_elem_owned for lp in lps) == conn.shape[0]
+    for lp in lps:
+        assert lp.n_interior > 0.5 * lp.n_owned                      # most rows can be assembled before the halo lands
+        assert lp.conn.shape[0] < 1.6 * lp.n_elem_owned               # one ghost layer, not more
+        assert 3 <= len(lp.recv_ids) <= 7                             # an octant of the cube touches the 7 others at most
+        for q, ids in lp.recv_ids.items():
+            np.testing.assert_array_equal(lp.node_global[ids], lps[q].node_global[lps[q].send_ids[lp.rank]])
+        for q, ids in lp.send_ids.items():
+            assert np.all(ids < lp.n_owned) and lp.rank in lps[q].recv_ids
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, 8, port, 6, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == 8 and all(ok for _, ok, _ in res)
