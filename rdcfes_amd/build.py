@@ -32,6 +32,8 @@ SOURCES = [
     "rdc_tet4_ev.hip",
     "rdc_prep_ev.cpp",
     "rdc_solid.hip",
+    "rdc_solid_cl.hip",
+    "rdc_prep_cl.cpp",
 ]
 
 ARCH = os.environ.get("RDC_OFFLOAD_ARCH", "gfx950")

@@ -75,7 +75,13 @@ struct rdc_ctx {
   DevBuf adpm_slot;
   DevBuf solid_ke, solid_fe, sg_gptr, sg_gsrc, sg_brow, solid_post;  // two-pass assembly: element matrices + gather lists
   bool solid_gather_ready = false;
-  int opt_solid_kernel = 0;  // 0 = two-pass (default), 1 = coloured read-modify-write
+  DevBuf scl_desc, scl_ntab, scl_eid, scl_pair, scl_pslot;           // fused cluster kernel (HEX8 tangent)
+  int solid_cl_state = 0;    // 0 = lists not built yet, 1 = ready, -1 = not available for this mesh (two-pass is used)
+  int solid_cl_waves = 31;   // consumer / producer waves the lists were built for (opt_solid_cl_waves at that time)
+  size_t scl_max_row_doubles = 0;
+  int scl_n_wg = 0;
+  int opt_solid_cl_waves = 31;  // 31 = 3 consumer + 1 producer waves (two workgroups per CU), 62 = 6 + 2 (one per CU)
+  int opt_solid_kernel = 0;  // 0 = default: fused cluster kernel for HEX8 tangent requests, two-pass otherwise; 1 = coloured read-modify-write; 2 = two-pass; 3 = fused (error if unavailable)
   int opt_solid_split = 1;   // two-pass, pass 1: 1 = one thread per element row (default; measured faster), 0 = HEX8 row columns split between two threads
   int opt_solid_store = 0;   // two-pass, pass 1 diagnostics (see SolidArgs::store_mode)
   int opt_solid_gather = 0;  // two-pass, pass 2: 0 = stores staged through LDS, 1 = direct 24-byte pieces
@@ -463,7 +469,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->pair_elem, &c->pair_local, &c->node_pair_ptr, &c->wg_node_ptr, &c->val, &c->rhs, &c->packed, &c->stamps, &c->rg2_desc, &c->rg2_pair, &c->rg2_chunk,
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg4_wgntab, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
-                   &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot,
+                   &c->scl_desc, &c->scl_ntab, &c->scl_eid, &c->scl_pair, &c->scl_pslot, &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot,
                    &c->ev_desc, &c->ev_nlist, &c->ev_vloc, &c->ev_vslot, &c->ev_ntab, &c->ev_perm};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
@@ -529,8 +535,11 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "solid_split")) c->opt_solid_split = value ? 1 : 0;
   else if (!std::strcmp(key, "solid_store")) c->opt_solid_store = value;
   else if (!std::strcmp(key, "solid_kernel")) {
-    if (value != 0 && value != 1) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (two-pass) or 1 (coloured)");
+    if (value < 0 || value > 3) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (default), 1 (coloured), 2 (two-pass) or 3 (fused cluster kernel)");
     c->opt_solid_kernel = value;
+  } else if (!std::strcmp(key, "solid_cl_waves")) {
+    if (value != 31 && value != 62) return fail(c, RDC_ERR_INVALID, "solid_cl_waves must be 31 (3 consumer + 1 producer waves) or 62");
+    c->opt_solid_cl_waves = value;
   }
   else if (!std::strcmp(key, "ev_occupancy")) c->opt_ev_occ = value;   // element-visit kernel: 3 (default, 168 registers) or 2
   else if (!std::strcmp(key, "ev_lds")) c->opt_ev_lds = value;   // LDS bytes per workgroup the element-visit clusters are sized for (next rdc_mesh_upload)
@@ -625,6 +634,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   c->n_materials = 0; c->n_sides = 0;
   c->have_mesh = true;
   c->solid_gather_ready = false;
+  c->solid_cl_state = 0;
   c->rg5_eid_ready = false;
   return RDC_OK;
 }
@@ -827,11 +837,54 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   a.stream = c->stream;
   a.colour_ptr = c->prep.colour_ptr.data();
   a.n_colours = c->prep.n_colours;
-  a.kernel = c->opt_solid_kernel;
   a.gather = c->opt_solid_gather;
   a.split = c->opt_solid_split;
   a.store_mode = c->opt_solid_store;
   a.nblocks = c->prep.bptr[(size_t)c->prep.n_owned];
+  // kernel choice: the fused cluster kernel serves HEX8 tangent requests; everything else is two-pass (or coloured on request)
+  int kernel = c->opt_solid_kernel == 1 ? 1 : 0;
+  if ((c->opt_solid_kernel == 0 || c->opt_solid_kernel == 3) && c->prep.nen == 8 && request_jacobian) {
+    if (c->solid_cl_state != 0 && c->solid_cl_waves != c->opt_solid_cl_waves) c->solid_cl_state = 0;
+    if (c->solid_cl_state == 0) {  // one-time: cluster lists
+      const int cw = c->opt_solid_cl_waves / 10, pw = c->opt_solid_cl_waves % 10;
+      HostPrepCl::Limits lim;
+      lim.max_nodes = cw * 8; lim.max_pairs = cw * 64; lim.max_elems = pw * 64;
+      lim.max_row_doubles = (int)(2 * pw * 64 * 49) - 3 * cw * 8 - 2;   // the image overlays the point buffers
+      HostPrepCl cl;
+      std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
+      RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      RDC_HIP(c, hipStreamSynchronize(c->stream));
+      const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl);
+      c->solid_cl_waves = c->opt_solid_cl_waves;
+      if (!err.empty()) {
+        c->solid_cl_state = -1;
+        if (c->opt_solid_kernel == 3) return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: %s", err.c_str());
+      } else {
+        if ((rc = dev_upload(c, c->scl_desc, cl.desc))) return rc;
+        if ((rc = dev_upload(c, c->scl_ntab, cl.ntab))) return rc;
+        if ((rc = dev_upload(c, c->scl_eid, cl.eid))) return rc;
+        if ((rc = dev_upload(c, c->scl_pair, cl.pair))) return rc;
+        if ((rc = dev_upload(c, c->scl_pslot, cl.pslot))) return rc;
+        RDC_HIP(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+        c->scl_max_row_doubles = cl.max_row_doubles;
+        c->scl_n_wg = (int)cl.desc.size();
+        c->solid_cl_state = 1;
+      }
+    }
+    if (c->solid_cl_state == 1) {
+      kernel = 3;
+      a.cl.n_wg = c->scl_n_wg; a.cl.cw = c->solid_cl_waves / 10; a.cl.pw = c->solid_cl_waves % 10;
+      a.cl.desc = (const HostPrepCl::Desc*)c->scl_desc.p;
+      a.cl.ntab = (const HostPrepCl::Node*)c->scl_ntab.p;
+      a.cl.eid = (const uint32_t*)c->scl_eid.p;
+      a.cl.pair = (const uint32_t*)c->scl_pair.p;
+      a.cl.pslot = (const uint32_t*)c->scl_pslot.p;
+      a.cl.max_row_doubles = c->scl_max_row_doubles;
+    }
+  } else if (c->opt_solid_kernel == 3) {
+    return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: HEX8 tangent requests only");
+  }
+  a.kernel = kernel;
   if (a.kernel == 0) {
     if (!c->solid_gather_ready) {  // one-time: gather lists and the element-matrix buffers
       SolidGather g;

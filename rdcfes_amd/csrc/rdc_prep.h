@@ -132,6 +132,38 @@ struct HostPrepEv {
 // n_interior >= 0: owned nodes [0, n_interior) are "interior" (two-part assembly): clusters do not mix the two kinds
 std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& out, int64_t n_interior = -1);
 
+// ---- node clusters with producer / consumer work lists (HEX8: rdc_solid_cl.hip, rdc_hex8_cl.hip) ------------------------
+// A workgroup owns a CLUSTER of owned nodes.  Its consumer lanes each take one (owned node, incident element) PAIR and
+// accumulate that row of the element matrix over the quadrature points; its producer lanes each take one ELEMENT
+// touching the cluster and evaluate the per-point data once per point for all the pairs of the element.
+struct HostPrepCl {
+  struct Limits { int max_nodes = 24, max_pairs = 192, max_elems = 64, max_row_doubles = 2600; };
+  struct Desc {            // 16 bytes per workgroup
+    uint16_t nown, npair, nelem, pad;
+    uint32_t row_doubles;  // LDS image of ONE equation row of all owned nodes: sum of nvar * len
+    uint32_t min_node_max_node_pad;
+  };
+  struct Node {            // 16 bytes per owned node of a workgroup
+    uint32_t bptr;         // first node block of the node's rows
+    uint16_t len;          // node blocks in the row
+    uint16_t off;          // offset (doubles) of the node's piece in the one-equation-row image
+    uint32_t node;         // node id
+    uint32_t pad;
+  };
+  bool ok = false;
+  Limits lim;
+  int nvar = 0;
+  std::vector<Desc> desc;
+  std::vector<Node> ntab;            // [n_wg][max_nodes]
+  std::vector<uint32_t> eid;         // [n_wg][max_elems] element ids, ~0u = none
+  std::vector<uint32_t> pair;        // [n_wg][max_pairs] local element | local row node << 8 | owned-node index << 16; ~0u = none
+  std::vector<uint32_t> pslot;       // [n_wg][max_pairs][nen / 4]: byte j = column slot of local node j in the pair's row
+  size_t max_row_doubles = 0;
+  // statistics
+  int64_t n_elem_visits = 0, n_pairs = 0;
+};
+std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPrepCl::Limits& lim, HostPrepCl& out);
+
 // returns empty string on success, else an error message
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,
                        int nvar, size_t lds_budget_bytes, int block, HostPrep& out, bool conflict_aware = true);

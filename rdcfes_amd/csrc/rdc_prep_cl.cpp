@@ -1,0 +1,205 @@
+// rdc_prep_cl.cpp — host preparation of the producer / consumer cluster kernels (rdc_solid_cl.hip): node clusters, their
+// element lists (producer lanes) and (node, element) pair lists (consumer lanes).
+//
+// Clusters are grown greedily over the mesh graph exactly as for the element-visit kernel (rdc_prep_ev.cpp): seed = the
+// unassigned owned node with the fewest unassigned neighbours (clusters grow along the front of what is assigned), then
+// the unassigned node sharing the most elements with the cluster joins until a limit binds (nodes, pairs, distinct
+// elements, LDS image of one equation row).  The fewer distinct elements per owned node, the less per-point work the
+// producers redo (a HEX8 brick of 4 x 3 x 2 nodes touches 60 elements = 2.5 per node, against 8 pairs per node).
+//
+// Pair order.  The consumers add their rows into the LDS image with ds_add_f64; a wave instruction is executed in four
+// groups of 16 lanes and lanes of a group hitting the same address (same node, same column) or the same double-bank
+// serialise (tools/lds_bank_model.hip).  The pairs are therefore listed "k-th pair of every node" major: any 16
+// consecutive pairs belong to 16 different nodes when the cluster has that many.
+#include <algorithm>
+#include <cstring>
+
+#include "rdc_prep.h"
+
+namespace rdc {
+
+std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPrepCl::Limits& lim, HostPrepCl& C) {
+  C = HostPrepCl();
+  C.lim = lim;
+  C.nvar = P.nvar;
+  const int nen = P.nen;
+  if (nen != 8 && nen != 4) return "cluster lists: TET4 / HEX8 only";
+  const int64_t n_elem = P.n_elem, n_node = P.n_node, n_owned = P.n_owned;
+  if (n_owned <= 0) return "no owned nodes";
+  if (P.bptr[(size_t)n_owned] >= ((int64_t)1 << 32)) return "more than 2^32 node blocks";
+  if (lim.max_nodes > 255 || lim.max_elems > 255 || lim.max_pairs > 65535) return "cluster limits out of range";
+  std::vector<int64_t> inc_ptr((size_t)n_node + 1, 0);
+  for (int64_t x = 0; x < n_elem * nen; x++) inc_ptr[conn[x] + 1]++;
+  for (int64_t n = 0; n < n_node; n++) inc_ptr[n + 1] += inc_ptr[n];
+  std::vector<uint32_t> inc((size_t)inc_ptr[n_node]);
+  {
+    std::vector<int64_t> fill(inc_ptr.begin(), inc_ptr.end() - 1);
+    for (int64_t e = 0; e < n_elem; e++)
+      for (int i = 0; i < nen; i++) inc[fill[conn[e * nen + i]]++] = (uint32_t)e;   // ascending element ids per node
+  }
+  for (int64_t n = 0; n < n_owned; n++) {
+    if (P.bptr[n + 1] - P.bptr[n] > 255) return "a row has more than 255 node blocks";
+    if (inc_ptr[n + 1] - inc_ptr[n] > lim.max_pairs || inc_ptr[n + 1] - inc_ptr[n] > lim.max_elems) return "a node has more incident elements than a cluster may hold";
+    if ((int64_t)P.nvar * (P.bptr[n + 1] - P.bptr[n]) > lim.max_row_doubles) return "a row exceeds the image budget";
+  }
+  // ---- greedy clustering ------------------------------------------------------------------------------------------
+  std::vector<int32_t> cluster_of((size_t)n_owned, -1);   // -1 unassigned, -2 rejected for the cluster being grown
+  std::vector<std::vector<uint32_t>> clusters;
+  {
+    std::vector<uint32_t> emark((size_t)n_elem, 0), gain((size_t)n_owned, 0), gstamp((size_t)n_owned, 0);
+    uint32_t stamp = 0;
+    std::vector<uint32_t> cand, rejected;
+    std::vector<int32_t> free_nb((size_t)n_owned, 0);
+    int max_nb = 0;
+    for (int64_t n = 0; n < n_owned; n++) {
+      int c = 0;
+      for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) c += (P.bcol[b] != (int32_t)n && (int64_t)P.bcol[b] < n_owned);
+      free_nb[n] = c;
+      max_nb = std::max(max_nb, c);
+    }
+    std::vector<std::vector<uint32_t>> bucket((size_t)max_nb + 1);
+    for (int64_t n = n_owned - 1; n >= 0; n--) bucket[(size_t)free_nb[n]].push_back((uint32_t)n);
+    auto assigned_update = [&](uint32_t n) {
+      for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) {
+        const int32_t m = P.bcol[b];
+        if (m == (int32_t)n || (int64_t)m >= n_owned || cluster_of[m] >= 0) continue;
+        free_nb[m]--;
+        bucket[(size_t)free_nb[m]].push_back((uint32_t)m);
+      }
+    };
+    int64_t n_assigned = 0;
+    while (n_assigned < n_owned) {
+      int64_t seed = -1;
+      for (size_t k = 0; k < bucket.size() && seed < 0; k++) {
+        while (!bucket[k].empty()) {
+          const uint32_t n = bucket[k].back();
+          bucket[k].pop_back();
+          if (cluster_of[n] < 0 && free_nb[n] == (int32_t)k) { seed = n; break; }
+        }
+      }
+      if (seed < 0) return "internal: seed queue ran dry";
+      stamp++;
+      std::vector<uint32_t> cl;
+      int64_t npair = 0, nel = 0, img = 0;
+      cand.clear();
+      rejected.clear();
+      auto new_elems = [&](uint32_t n) {
+        int64_t d = 0;
+        for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) d += (emark[inc[k]] != stamp);
+        return d;
+      };
+      auto add = [&](uint32_t n) {
+        cluster_of[n] = (int32_t)clusters.size();
+        cl.push_back(n);
+        n_assigned++;
+        assigned_update(n);
+        npair += inc_ptr[n + 1] - inc_ptr[n];
+        img += (int64_t)P.nvar * (P.bptr[n + 1] - P.bptr[n]);
+        for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
+          const uint32_t e = inc[k];
+          if (emark[e] == stamp) continue;
+          emark[e] = stamp;
+          nel++;
+          for (int j = 0; j < nen; j++) {
+            const uint32_t m = conn[(int64_t)e * nen + j];
+            if ((int64_t)m < n_owned && cluster_of[m] == -1) {
+              if (gstamp[m] != stamp) { gstamp[m] = stamp; gain[m] = 0; cand.push_back(m); }
+              gain[m]++;
+            }
+          }
+        }
+      };
+      add((uint32_t)seed);
+      while ((int)cl.size() < lim.max_nodes) {
+        int best = -1;
+        for (size_t x = 0; x < cand.size(); x++) {
+          const uint32_t c = cand[x];
+          if (cluster_of[c] != -1) continue;
+          if (best < 0) { best = (int)x; continue; }
+          const uint32_t bc = cand[(size_t)best];
+          if (gain[c] > gain[bc] || (gain[c] == gain[bc] && (free_nb[c] < free_nb[bc] || (free_nb[c] == free_nb[bc] && c < bc)))) best = (int)x;
+        }
+        if (best < 0) break;
+        const uint32_t c = cand[(size_t)best];
+        if (npair + (inc_ptr[c + 1] - inc_ptr[c]) > lim.max_pairs || nel + new_elems(c) > lim.max_elems ||
+            img + (int64_t)P.nvar * (P.bptr[c + 1] - P.bptr[c]) > lim.max_row_doubles) {
+          cluster_of[c] = -2;
+          rejected.push_back(c);
+          continue;
+        }
+        add(c);
+      }
+      for (uint32_t c : rejected) cluster_of[c] = -1;
+      clusters.push_back(std::move(cl));
+    }
+  }
+  const int64_t nwg = (int64_t)clusters.size();
+  // ---- per-workgroup lists ------------------------------------------------------------------------------------------
+  C.desc.assign((size_t)nwg, HostPrepCl::Desc{0, 0, 0, 0, 0, 0});
+  C.ntab.assign((size_t)nwg * lim.max_nodes, HostPrepCl::Node{0, 0, 0, 0, 0});
+  C.eid.assign((size_t)nwg * lim.max_elems, 0xFFFFFFFFu);
+  C.pair.assign((size_t)nwg * lim.max_pairs, 0xFFFFFFFFu);
+  const int wpp = nen / 4;
+  C.pslot.assign((size_t)nwg * lim.max_pairs * wpp, 0);
+  int fail = 0;
+  std::vector<uint32_t> rowd((size_t)nwg, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t w = 0; w < nwg; w++) {
+    const std::vector<uint32_t>& cl = clusters[(size_t)w];
+    std::vector<uint32_t> el;
+    size_t maxinc = 0;
+    for (uint32_t n : cl) {
+      for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) el.push_back(inc[k]);
+      maxinc = std::max(maxinc, (size_t)(inc_ptr[n + 1] - inc_ptr[n]));
+    }
+    std::sort(el.begin(), el.end());
+    el.erase(std::unique(el.begin(), el.end()), el.end());
+    if ((int)el.size() > lim.max_elems || (int)cl.size() > lim.max_nodes) { fail = 1; continue; }
+    HostPrepCl::Desc& d = C.desc[(size_t)w];
+    d.nown = (uint16_t)cl.size();
+    d.nelem = (uint16_t)el.size();
+    std::copy(el.begin(), el.end(), C.eid.begin() + (size_t)w * lim.max_elems);
+    uint32_t off = 0;
+    for (size_t a = 0; a < cl.size(); a++) {
+      const uint32_t n = cl[a];
+      HostPrepCl::Node& nd = C.ntab[(size_t)w * lim.max_nodes + a];
+      const int64_t len = P.bptr[n + 1] - P.bptr[n];
+      nd.bptr = (uint32_t)P.bptr[n]; nd.len = (uint16_t)len; nd.off = (uint16_t)off; nd.node = n;
+      off += (uint32_t)(P.nvar * len);
+    }
+    if (off > 0xFFFFu) { fail = 1; continue; }
+    d.row_doubles = off;
+    rowd[(size_t)w] = off;
+    // pairs: k-th incident element of every node, k-major
+    uint32_t np = 0;
+    for (size_t k = 0; k < maxinc; k++)
+      for (size_t a = 0; a < cl.size(); a++) {
+        const uint32_t n = cl[a];
+        if ((int64_t)k >= inc_ptr[n + 1] - inc_ptr[n]) continue;
+        const uint32_t e = inc[inc_ptr[n] + (int64_t)k];
+        int li = -1;
+        for (int j = 0; j < nen; j++) if (conn[(int64_t)e * nen + j] == n) { li = j; break; }
+        // a node listed twice in one element would need two pairs with the same element: not a valid mesh
+        const uint32_t le = (uint32_t)(std::lower_bound(el.begin(), el.end(), e) - el.begin());
+        if (li < 0 || np >= (uint32_t)lim.max_pairs) { fail = 1; break; }
+        C.pair[(size_t)w * lim.max_pairs + np] = le | ((uint32_t)li << 8) | ((uint32_t)a << 16);
+        for (int j = 0; j < nen; j++) {
+          const uint32_t s = P.eslot[(size_t)e * nen * nen + (size_t)li * nen + j];
+          if (s > 255) fail = 1;
+          C.pslot[((size_t)w * lim.max_pairs + np) * wpp + j / 4] |= (s & 0xFFu) << (8 * (j % 4));
+        }
+        np++;
+      }
+    d.npair = (uint16_t)np;
+  }
+  if (fail) return "internal: cluster list construction failed";
+  for (int64_t w = 0; w < nwg; w++) {
+    C.max_row_doubles = std::max(C.max_row_doubles, (size_t)rowd[(size_t)w]);
+    C.n_elem_visits += C.desc[(size_t)w].nelem;
+    C.n_pairs += C.desc[(size_t)w].npair;
+  }
+  C.ok = true;
+  return std::string();
+}
+
+}  // namespace rdc

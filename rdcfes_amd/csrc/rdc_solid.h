@@ -3,6 +3,16 @@
 #define RDC_SOLID_H
 #include "rdc_internal.h"
 namespace rdc {
+// device view of the cluster lists (HostPrepCl) of the fused HEX8 kernel (rdc_solid_cl.hip)
+struct SolidClDev {
+  int n_wg = 0, cw = 3, pw = 1;     // consumer / producer waves per workgroup the lists were built for
+  const HostPrepCl::Desc* desc = nullptr;
+  const HostPrepCl::Node* ntab = nullptr;
+  const uint32_t* eid = nullptr;
+  const uint32_t* pair = nullptr;
+  const uint32_t* pslot = nullptr;
+  size_t max_row_doubles = 0;
+};
 struct SolidArgs {
   MeshDev m;
   int nen;
@@ -21,7 +31,8 @@ struct SolidArgs {
   hipStream_t stream;
   const int64_t* colour_ptr;   // host
   int n_colours;
-  int kernel;                  // 0 = two-pass (element matrices + gather), 1 = coloured read-modify-write
+  int kernel;                  // 0 = two-pass (element matrices + gather), 1 = coloured read-modify-write, 3 = fused cluster kernel (HEX8 tangent)
+  SolidClDev cl;
   double* ke;                  // [n_elem][nen][nen][3][3] element matrices (two-pass)
   double* fe;                  // [n_elem][nen][3]
   int64_t nblocks;             // node blocks of the owned rows
@@ -33,6 +44,8 @@ struct SolidArgs {
   int gather;                  // pass 2: 0 = stores staged through LDS (runs of consecutive doubles), 1 = 24-byte pieces
 };
 hipError_t launch_solid(const SolidArgs& a);
+hipError_t launch_solid_cl(const SolidArgs& a);   // element part only (rdc_solid_cl.hip); launch_solid adds the sides
+size_t solid_cl_lds_bytes(int cw, int pw, size_t max_row_doubles);
 hipError_t launch_solid_post(const SolidArgs& a, double* out /* [n_elem][5] device */);
 }  // namespace rdc
 #endif

@@ -780,7 +780,10 @@ hipError_t launch_solid_post(const SolidArgs& a, double* out) {
 }
 
 hipError_t launch_solid(const SolidArgs& a) {
-  if (a.kernel == 0) {
+  if (a.kernel == 3) {
+    const hipError_t e = launch_solid_cl(a);
+    if (e != hipSuccess) return e;
+  } else if (a.kernel == 0) {
     if (a.nen == 4) launch_two_pass<4>(a); else launch_two_pass<8>(a);
   } else
   for (int c = 0; c < a.n_colours; c++) {

@@ -46,7 +46,7 @@ def build_shim():
     bdir.mkdir(exist_ok=True)
     so = bdir / "libhost_shim.so"
     srcs = [ROOT / "tests" / "host_shim.cpp", ROOT / "rdcfes_amd" / "csrc" / "rdc_meshprep.cpp",
-            ROOT / "rdcfes_amd" / "csrc" / "rdc_prep_ev.cpp"]
+            ROOT / "rdcfes_amd" / "csrc" / "rdc_prep_ev.cpp", ROOT / "rdcfes_amd" / "csrc" / "rdc_prep_cl.cpp"]
     deps = srcs + list((ROOT / "rdcfes_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "rdc_assembly.h"]
     if not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in deps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wno-unknown-pragmas",

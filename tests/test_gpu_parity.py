@@ -182,14 +182,16 @@ def _solid_case(nen, n, seed=0):
 @pytest.mark.parametrize("nen,n", [(8, 5), (4, 4)])
 @pytest.mark.parametrize("use_symmetry", [0, 1])
 @pytest.mark.parametrize("jac", [True, False])
-@pytest.mark.parametrize("solid_kernel,solid_gather,solid_split", [(0, 0, 0), (0, 1, 1), (1, 0, 0)])
-def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel, solid_gather, solid_split):
+@pytest.mark.parametrize("solid_kernel,solid_gather,solid_split,cl_waves",
+                         [(0, 0, 0, 31), (0, 0, 0, 62), (2, 0, 0, 31), (2, 1, 1, 31), (1, 0, 0, 31)])
+def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel, solid_gather, solid_split, cl_waves):
     conn, Xu, x, em, mats, fibre, sides = _solid_case(nen, n)
     sp = SolidParams(0.4, 1.0e5, use_symmetry, 0)
     _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_SOLID, nen, conn, x, 3, sp, xyz_undeformed=Xu, elem_fibre=fibre,
                                        elem_material=em, materials=mats, request_jacobian=jac, sides=sides)
     with AssemblyContext(0) as ctx:
-        ctx.set_option("solid_kernel", solid_kernel)   # 0 = two-pass (default), 1 = coloured
+        ctx.set_option("solid_kernel", solid_kernel)   # 0 = default (fused cluster kernel for HEX8 tangents, else two-pass), 1 = coloured, 2 = two-pass
+        ctx.set_option("solid_cl_waves", cl_waves)     # fused kernel: 31 = 3 consumer + 1 producer waves, 62 = 6 + 2
         ctx.set_option("solid_gather", solid_gather)   # pass 2: 0 = stores staged through LDS (default), 1 = direct
         ctx.set_option("solid_split", solid_split)     # pass 1: 0 = HEX8 row split over two threads (default), 1 = not
         ctx.mesh_upload(nen, conn, x, 3)
@@ -206,7 +208,7 @@ def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel, solid_gat
         assert rel(val, val0) < TOL
     else:
         assert np.all(val == 0.0)
-    if solid_kernel == 0 and sides[0].size == 0:
+    if solid_kernel == 2 and sides[0].size == 0:
         assert np.array_equal(val, val2) and np.array_equal(rhs, rhs2)
     else:
         assert rel(rhs2, rhs0) < TOL

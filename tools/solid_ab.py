@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pass-1 / pass-2 timing of the two-pass solid assembly under diagnostic options (tools/perf_table.py set-up)."""
+"""Fused cluster kernel vs the two-pass solid assembly (and its diagnostic options) on H(n), interleaved rounds."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -16,13 +16,14 @@ with AssemblyContext(0) as c:
     c.mesh_upload(8, conn, x, 3)
     c.field_upload(FIELD_UNDEFORMED_XYZ, Xu); c.field_upload(FIELD_ELEM_FIBRE, np.tile([0.0, 0.0, 1.0], (conn.shape[0], 1)))
     c.solid_set_materials(em, mats)
-    for name, opts in (("default", {}), ("gather=1 (direct stores)", {"solid_gather": 1}), ("pass 1 direct stores", {"solid_store": 1}),
-                       ("pass 1 without stores", {"solid_store": 2}), ("column split", {"solid_split": 0})):
-        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0)
+    for rnd in range(2):
+      for name, opts in (("fused 3+1 waves (default)", {}), ("fused 6+2 waves", {"solid_cl_waves": 62}), ("two-pass", {"solid_kernel": 2}),
+                         ("two-pass, pass 1 without stores", {"solid_kernel": 2, "solid_store": 2})):
+        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31)
         for k, v in opts.items(): c.set_option(k, v)
         c.solid_assemble(sp, True); c.synchronize()
         c.timing_enable(True)
         for _ in range(3): c.solid_assemble(sp, True)
         ms, cnt = c.timing_sum_ms()
         c.timing_enable(False)
-        print(f"{name:24s} {ms / cnt:8.3f} ms (pass 1 + gather + rhs)", flush=True)
+        print(f"{name:34s} {ms / cnt:8.3f} ms", flush=True)
