@@ -80,6 +80,8 @@ struct rdc_ctx {
   int solid_cl_waves = 31;   // consumer / producer waves the lists were built for (opt_solid_cl_waves at that time)
   size_t scl_max_row_doubles = 0;
   int scl_n_wg = 0;
+  int opt_solid_cl_order = 1;   // pair order of the cluster lists (rdc_prep_cl.cpp): 1 = element-major over colour-sorted elements, 0 = node-distinct
+  int solid_cl_order = 1;
   int opt_solid_cl_waves = 31;  // 31 = 3 consumer + 1 producer waves (two workgroups per CU), 62 = 6 + 2 (one per CU)
   int opt_solid_kernel = 0;  // 0 = default: fused cluster kernel for HEX8 tangent requests, two-pass otherwise; 1 = coloured read-modify-write; 2 = two-pass; 3 = fused (error if unavailable)
   int opt_solid_split = 1;   // two-pass, pass 1: 1 = one thread per element row (default; measured faster), 0 = HEX8 row columns split between two threads
@@ -537,6 +539,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "solid_kernel")) {
     if (value < 0 || value > 3) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (default), 1 (coloured), 2 (two-pass) or 3 (fused cluster kernel)");
     c->opt_solid_kernel = value;
+  } else if (!std::strcmp(key, "solid_cl_order")) {
+    c->opt_solid_cl_order = value ? 1 : 0;
   } else if (!std::strcmp(key, "solid_cl_waves")) {
     if (value != 31 && value != 62) return fail(c, RDC_ERR_INVALID, "solid_cl_waves must be 31 (3 consumer + 1 producer waves) or 62");
     c->opt_solid_cl_waves = value;
@@ -844,18 +848,20 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   // kernel choice: the fused cluster kernel serves HEX8 tangent requests; everything else is two-pass (or coloured on request)
   int kernel = c->opt_solid_kernel == 1 ? 1 : 0;
   if ((c->opt_solid_kernel == 0 || c->opt_solid_kernel == 3) && c->prep.nen == 8 && request_jacobian) {
-    if (c->solid_cl_state != 0 && c->solid_cl_waves != c->opt_solid_cl_waves) c->solid_cl_state = 0;
+    if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != c->opt_solid_cl_order)) c->solid_cl_state = 0;
     if (c->solid_cl_state == 0) {  // one-time: cluster lists
       const int cw = c->opt_solid_cl_waves / 10, pw = c->opt_solid_cl_waves % 10;
       HostPrepCl::Limits lim;
       lim.max_nodes = cw * 8; lim.max_pairs = cw * 64; lim.max_elems = pw * 64;
       lim.max_row_doubles = (int)(2 * pw * 64 * 49) - 3 * cw * 8 - 2;   // the image overlays the point buffers
+      lim.pair_order = c->opt_solid_cl_order;
       HostPrepCl cl;
       std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
       RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       RDC_HIP(c, hipStreamSynchronize(c->stream));
       const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl);
       c->solid_cl_waves = c->opt_solid_cl_waves;
+      c->solid_cl_order = c->opt_solid_cl_order;
       if (!err.empty()) {
         c->solid_cl_state = -1;
         if (c->opt_solid_kernel == 3) return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: %s", err.c_str());

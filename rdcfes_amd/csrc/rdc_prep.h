@@ -137,16 +137,16 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
 // accumulate that row of the element matrix over the quadrature points; its producer lanes each take one ELEMENT
 // touching the cluster and evaluate the per-point data once per point for all the pairs of the element.
 struct HostPrepCl {
-  struct Limits { int max_nodes = 24, max_pairs = 192, max_elems = 64, max_row_doubles = 2600; };
+  struct Limits { int max_nodes = 24, max_pairs = 192, max_elems = 64, max_row_doubles = 6000, pair_order = 1; };   // max_row_doubles: LDS image of the cluster's CSR rows
   struct Desc {            // 16 bytes per workgroup
     uint16_t nown, npair, nelem, pad;
-    uint32_t row_doubles;  // LDS image of ONE equation row of all owned nodes: sum of nvar * len
+    uint32_t row_doubles;  // LDS image of the CSR rows of all owned nodes: sum of nvar^2 * len
     uint32_t min_node_max_node_pad;
   };
   struct Node {            // 16 bytes per owned node of a workgroup
     uint32_t bptr;         // first node block of the node's rows
     uint16_t len;          // node blocks in the row
-    uint16_t off;          // offset (doubles) of the node's piece in the one-equation-row image
+    uint16_t off;          // offset (doubles) of the node's rows in the image (same layout as in the CSR array)
     uint32_t node;         // node id
     uint32_t pad;
   };
@@ -156,7 +156,7 @@ struct HostPrepCl {
   std::vector<Desc> desc;
   std::vector<Node> ntab;            // [n_wg][max_nodes]
   std::vector<uint32_t> eid;         // [n_wg][max_elems] element ids, ~0u = none
-  std::vector<uint32_t> pair;        // [n_wg][max_pairs] local element | local row node << 8 | owned-node index << 16; ~0u = none
+  std::vector<uint32_t> pair;        // [n_wg][max_pairs] local element | local row node << 8 | owned-node index << 16; ~0u = none (order: rdc_prep_cl.cpp)
   std::vector<uint32_t> pslot;       // [n_wg][max_pairs][nen / 4]: byte j = column slot of local node j in the pair's row
   size_t max_row_doubles = 0;
   // statistics

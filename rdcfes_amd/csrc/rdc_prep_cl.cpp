@@ -4,13 +4,20 @@
 // Clusters are grown greedily over the mesh graph exactly as for the element-visit kernel (rdc_prep_ev.cpp): seed = the
 // unassigned owned node with the fewest unassigned neighbours (clusters grow along the front of what is assigned), then
 // the unassigned node sharing the most elements with the cluster joins until a limit binds (nodes, pairs, distinct
-// elements, LDS image of one equation row).  The fewer distinct elements per owned node, the less per-point work the
+// elements, LDS image of the cluster's CSR rows).  The fewer distinct elements per owned node, the less per-point work the
 // producers redo (a HEX8 brick of 4 x 3 x 2 nodes touches 60 elements = 2.5 per node, against 8 pairs per node).
 //
-// Pair order.  The consumers add their rows into the LDS image with ds_add_f64; a wave instruction is executed in four
-// groups of 16 lanes and lanes of a group hitting the same address (same node, same column) or the same double-bank
-// serialise (tools/lds_bank_model.hip).  The pairs are therefore listed "k-th pair of every node" major: any 16
-// consecutive pairs belong to 16 different nodes when the cluster has that many.
+// Pair order.  Two LDS access patterns depend on it:
+//  (a) a consumer lane reads the 47-double point record of its element at every point (376 ds_read_b64 per pair, the bulk
+//      of the kernel's LDS traffic).  Records are 49 doubles apart, so the records of 32 CONSECUTIVE local elements start in
+//      32 different double-banks; lanes reading the same record broadcast;
+//  (b) the consumers add their rows into the LDS image with ds_add_f64, executed in four groups of 16 lanes; lanes of a
+//      group hitting the same address (same node, same column) or the same double-bank serialise (tools/lds_bank_model.hip).
+// pair_order 1 (default): elements sorted by (colour, id) -- elements of one colour share no node -- and the pairs listed
+// element after element: the 32 lanes of a read pass cover a run of consecutive records (conflict-free), and the ~5
+// elements of a 16-lane group are node-disjoint, so no two lanes of an atomic pass share a row.
+// pair_order 0: "k-th pair of every node" major (16 consecutive pairs = 16 different, consecutive nodes: atomics free of
+// conflicts, but a read pass then touches ~20 scattered records and 39% of the LDS cycles were bank conflicts).
 #include <algorithm>
 #include <cstring>
 
@@ -40,7 +47,7 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
   for (int64_t n = 0; n < n_owned; n++) {
     if (P.bptr[n + 1] - P.bptr[n] > 255) return "a row has more than 255 node blocks";
     if (inc_ptr[n + 1] - inc_ptr[n] > lim.max_pairs || inc_ptr[n + 1] - inc_ptr[n] > lim.max_elems) return "a node has more incident elements than a cluster may hold";
-    if ((int64_t)P.nvar * (P.bptr[n + 1] - P.bptr[n]) > lim.max_row_doubles) return "a row exceeds the image budget";
+    if ((int64_t)P.nvar * P.nvar * (P.bptr[n + 1] - P.bptr[n]) > lim.max_row_doubles) return "the rows of one node exceed the image budget";
   }
   // ---- greedy clustering ------------------------------------------------------------------------------------------
   std::vector<int32_t> cluster_of((size_t)n_owned, -1);   // -1 unassigned, -2 rejected for the cluster being grown
@@ -94,7 +101,7 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
         n_assigned++;
         assigned_update(n);
         npair += inc_ptr[n + 1] - inc_ptr[n];
-        img += (int64_t)P.nvar * (P.bptr[n + 1] - P.bptr[n]);
+        img += (int64_t)P.nvar * P.nvar * (P.bptr[n + 1] - P.bptr[n]);
         for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
           const uint32_t e = inc[k];
           if (emark[e] == stamp) continue;
@@ -122,7 +129,7 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
         if (best < 0) break;
         const uint32_t c = cand[(size_t)best];
         if (npair + (inc_ptr[c + 1] - inc_ptr[c]) > lim.max_pairs || nel + new_elems(c) > lim.max_elems ||
-            img + (int64_t)P.nvar * (P.bptr[c + 1] - P.bptr[c]) > lim.max_row_doubles) {
+            img + (int64_t)P.nvar * P.nvar * (P.bptr[c + 1] - P.bptr[c]) > lim.max_row_doubles) {
           cluster_of[c] = -2;
           rejected.push_back(c);
           continue;
@@ -154,6 +161,8 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
     }
     std::sort(el.begin(), el.end());
     el.erase(std::unique(el.begin(), el.end()), el.end());
+    if (lim.pair_order == 1)
+      std::sort(el.begin(), el.end(), [&](uint32_t x, uint32_t y) { return P.colour[x] != P.colour[y] ? P.colour[x] < P.colour[y] : x < y; });
     if ((int)el.size() > lim.max_elems || (int)cl.size() > lim.max_nodes) { fail = 1; continue; }
     HostPrepCl::Desc& d = C.desc[(size_t)w];
     d.nown = (uint16_t)cl.size();
@@ -165,31 +174,45 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
       HostPrepCl::Node& nd = C.ntab[(size_t)w * lim.max_nodes + a];
       const int64_t len = P.bptr[n + 1] - P.bptr[n];
       nd.bptr = (uint32_t)P.bptr[n]; nd.len = (uint16_t)len; nd.off = (uint16_t)off; nd.node = n;
-      off += (uint32_t)(P.nvar * len);
+      off += (uint32_t)(P.nvar * P.nvar * len);
     }
     if (off > 0xFFFFu) { fail = 1; continue; }
     d.row_doubles = off;
     rowd[(size_t)w] = off;
-    // pairs: k-th incident element of every node, k-major
     uint32_t np = 0;
-    for (size_t k = 0; k < maxinc; k++)
-      for (size_t a = 0; a < cl.size(); a++) {
-        const uint32_t n = cl[a];
-        if ((int64_t)k >= inc_ptr[n + 1] - inc_ptr[n]) continue;
-        const uint32_t e = inc[inc_ptr[n] + (int64_t)k];
-        int li = -1;
-        for (int j = 0; j < nen; j++) if (conn[(int64_t)e * nen + j] == n) { li = j; break; }
-        // a node listed twice in one element would need two pairs with the same element: not a valid mesh
-        const uint32_t le = (uint32_t)(std::lower_bound(el.begin(), el.end(), e) - el.begin());
-        if (li < 0 || np >= (uint32_t)lim.max_pairs) { fail = 1; break; }
-        C.pair[(size_t)w * lim.max_pairs + np] = le | ((uint32_t)li << 8) | ((uint32_t)a << 16);
-        for (int j = 0; j < nen; j++) {
-          const uint32_t s = P.eslot[(size_t)e * nen * nen + (size_t)li * nen + j];
-          if (s > 255) fail = 1;
-          C.pslot[((size_t)w * lim.max_pairs + np) * wpp + j / 4] |= (s & 0xFFu) << (8 * (j % 4));
-        }
-        np++;
+    auto emit = [&](uint32_t le, int li, size_t a) {
+      const uint32_t e = el[le];
+      if (np >= (uint32_t)lim.max_pairs) { fail = 1; return; }
+      C.pair[(size_t)w * lim.max_pairs + np] = le | ((uint32_t)li << 8) | ((uint32_t)a << 16);
+      for (int j = 0; j < nen; j++) {
+        const uint32_t s = P.eslot[(size_t)e * nen * nen + (size_t)li * nen + j];
+        if (s > 255) fail = 1;
+        C.pslot[((size_t)w * lim.max_pairs + np) * wpp + j / 4] |= (s & 0xFFu) << (8 * (j % 4));
       }
+      np++;
+    };
+    if (lim.pair_order == 1) {
+      // element after element (a node listed twice in one element is not a valid mesh: one pair per (element, local node))
+      for (uint32_t le = 0; le < (uint32_t)el.size(); le++)
+        for (int li = 0; li < nen; li++) {
+          const uint32_t n = conn[(int64_t)el[le] * nen + li];
+          if ((int64_t)n >= n_owned || cluster_of[n] != (int32_t)w) continue;
+          emit(le, li, (size_t)(std::find(cl.begin(), cl.end(), n) - cl.begin()));
+        }
+    } else {
+      // k-th incident element of every node, k-major
+      for (size_t k = 0; k < maxinc; k++)
+        for (size_t a = 0; a < cl.size(); a++) {
+          const uint32_t n = cl[a];
+          if ((int64_t)k >= inc_ptr[n + 1] - inc_ptr[n]) continue;
+          const uint32_t e = inc[inc_ptr[n] + (int64_t)k];
+          int li = -1;
+          for (int j = 0; j < nen; j++) if (conn[(int64_t)e * nen + j] == n) { li = j; break; }
+          const uint32_t le = (uint32_t)(std::find(el.begin(), el.end(), e) - el.begin());
+          if (li < 0) { fail = 1; break; }
+          emit(le, li, a);
+        }
+    }
     d.npair = (uint16_t)np;
   }
   if (fail) return "internal: cluster list construction failed";

@@ -14,10 +14,10 @@
 //     not compete with the 144 accumulator registers of the consumers; both fit 256 VGPRs, two workgroups per CU.
 //     The point buffer is double-buffered: producers fill point q + 1 while consumers accumulate point q, one
 //     workgroup barrier per point;
-//   * epilogue: per equation row r = 0..2 the consumers add their 24 values into an LDS image of that row of all owned
-//     nodes (ds_add_f64; pair order chosen on the host so that the 16 lanes of an LDS pass hit 16 different nodes), and
-//     the image leaves as runs of 3 * len consecutive doubles per node.  Every CSR value is written exactly once, no
-//     global atomics, nothing is read back.
+//   * epilogue: the consumers add their 72 values into an LDS image of the CSR rows of all owned nodes (ds_add_f64;
+//     the image overlays the point buffers; pair order chosen on the host so that the 16 lanes of an LDS pass hit
+//     different rows), and the image leaves as one run of 9 * len consecutive doubles per node.  Every CSR value is
+//     written exactly once, no global atomics, nothing is read back.
 // The summation order inside a node block depends on the LDS atomics' arrival order: results are reproducible to
 // rounding, not bitwise (the two-pass form, solid_kernel = 2, is).
 #include "rdc_solid.h"
@@ -39,29 +39,33 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
   constexpr int MAXP = CW * 64, MAXE = PW * 64, MAXN = CW * 8, NT = (CW + PW) * 64;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int w = blockIdx.x;
-  const int tid = threadIdx.x;
+  // Roles rotate over the waves from workgroup to workgroup: the hardware places wave i of every workgroup on SIMD i,
+  // so with fixed roles the producers of the two workgroups of a CU (the longer instruction stream) would share a SIMD.
+  constexpr int NW = CW + PW;
+  const int tid = (int)(((threadIdx.x >> 6) + ((blockIdx.x >> 3) % NW)) % NW) * 64 + (int)(threadIdx.x & 63);
   const HostPrepCl::Desc d = desc[w];
   const bool producer = tid >= MAXP;
   const int nimg = (int)d.row_doubles;
   double* const img = lds;
   double* const lrhs = lds + ((nimg + 1) & ~1);
-  // the image of one equation row of all owned nodes overlays the point buffers once the points are consumed
+  // the image of the CSR rows of all owned nodes overlays the point buffers once the points are consumed
   auto zero_image = [&]() {
-    for (int x = tid; x < ((nimg + 1) & ~1) + 3 * (int)d.nown; x += NT) lds[x] = 0.0;
+    cl_v2d* z = reinterpret_cast<cl_v2d*>(lds);
+    const cl_v2d zero = {0.0, 0.0};
+    for (int x = tid; x < (((nimg + 1) & ~1) + 3 * (int)d.nown + 1) / 2; x += NT) z[x] = zero;
   };
-  // a half-wave per node: its piece of equation row r is 3 * len consecutive doubles of the CSR array
-  auto copy_out = [&](int r) {
+  // a half-wave per node: its three rows are 9 * len consecutive doubles of the CSR array
+  auto copy_out = [&]() {
     for (int a = tid >> 5; a < (int)d.nown; a += NT / 32) {
       const HostPrepCl::Node nd = ntab[(size_t)w * MAXN + a];
-      const int n3 = 3 * (int)nd.len;
-      double* dst = val + 9 * (int64_t)nd.bptr + (int64_t)r * n3;
-      for (int k = tid & 31; k < n3; k += 32) {
-        __builtin_nontemporal_store(img[nd.off + k], dst + k);
-        img[nd.off + k] = 0.0;
-      }
-      if (r == 0 && (tid & 31) < 3) rhs[3 * (int64_t)nd.node + (tid & 31)] = lrhs[3 * a + (tid & 31)];
+      const int n9 = 9 * (int)nd.len;
+      double* dst = val + 9 * (int64_t)nd.bptr;
+      for (int k = tid & 31; k < n9; k += 32) __builtin_nontemporal_store(img[nd.off + k], dst + k);
+      if ((tid & 31) < 3) rhs[3 * (int64_t)nd.node + (tid & 31)] = lrhs[3 * a + (tid & 31)];
     }
   };
+  // workgroup barrier that orders LDS accesses only (no wait for the global stores in flight)
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // The two roles are separate code paths with the SAME sequence of workgroup barriers (the branch is uniform per wave),
   // so that the register allocator never has to hold the consumers' accumulators and the producers' element together.
   if (producer) {
@@ -70,7 +74,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
     const uint32_t e = eid[(size_t)w * MAXE + pl];
     const bool plive = e != 0xFFFFFFFFu;
     double X[8][3], XU[8][3];
-    double mu = 0.0, lame = 0.0, Kf = 0.0, A[3] = {0.0, 0.0, 0.0}, lam[3] = {1.0, 1.0, 1.0};
+    double mu = 0.0, lame = 0.0, Kf = 0.0, A[3] = {0.0, 0.0, 0.0}, lam[3] = {1.0, 1.0, 1.0}, rlam = 1.0;
     if (plive) {
 #pragma unroll
       for (int n = 0; n < 8; n++) {
@@ -90,6 +94,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
       }
 #pragma unroll
       for (int c = 0; c < 3; c++) lam[c] = 1.0 + pseudo_time * mat.rate[c];  // solid_system.C:232-234
+      rlam = 1.0 / (lam[0] * lam[1] * lam[2]);
     }
     // one quadrature point of the element -> record in buffer b
     auto produce = [&](int q, int b) {
@@ -120,10 +125,10 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
       F[2][0] = c02 * s;
       F[2][1] = (gX[0][1] * gX[2][0] - gX[0][0] * gX[2][1]) * s;
       F[2][2] = (gX[0][0] * gX[1][1] - gX[0][1] * gX[1][0]) * s;
-      const double detF = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) +
-                          F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
-      const double Jr = 1.0 / detF;
-      const double Je = detF / (lam[0] * lam[1] * lam[2]);
+      // det F = 1 / det gradX exactly (F = gradX^-1); the reference evaluates the determinant of F itself, equal to rounding
+      const double dgX = gX[0][0] * c00 + gX[0][1] * c01 + gX[0][2] * c02;
+      const double Jr = dgX;                 // 1 / det F
+      const double Je = s * rlam;            // det F / (lam0 lam1 lam2)
       double M[3][3], fa[3];
 #pragma unroll
       for (int i = 0; i < 3; i++) {
@@ -132,10 +137,11 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
         for (int j = 0; j < 3; j++)
           M[i][j] = F[i][0] * lam[0] * gX[0][j] + F[i][1] * lam[1] * gX[1][j] + F[i][2] * lam[2] * gX[2][j];
       }
-      const double dWdJe = (-mu / Je) + (lame / 2.0 * Je - lame / 2.0 / Je);          // hyperlastic_inline.h:42
-      const double d2W = (mu / Je / Je) + (lame / 2.0 + lame / 2.0 / Je / Je);        // :47
-      const double beta = Je * dWdJe;
-      const double alpha = beta + Je * Je * d2W;
+      // beta = Je dW/dJe and alpha = beta + Je^2 d2W/dJe^2 of hyperlastic_inline.h:42,47 in closed form (no divisions):
+      //   dW/dJe = -mu/Je + lame/2 (Je - 1/Je),  d2W/dJe^2 = mu/Je^2 + lame/2 (1 + 1/Je^2)
+      const double Je2 = Je * Je;
+      const double beta = 0.5 * lame * (Je2 - 1.0) - mu;
+      const double alpha = lame * Je2;
       double* pd = lds + (b * MAXE + pl) * PSTRIDE;
 #pragma unroll
       for (int n = 0; n < 8; n++)
@@ -165,13 +171,9 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
       __syncthreads();
     }
     zero_image();
-    __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < 3; r++) {
-      __syncthreads();              // consumers: atomics of equation row r
-      copy_out(r);
-      if (r < 2) __syncthreads();
-    }
+    lds_barrier();
+    lds_barrier();                  // consumers: atomics
+    copy_out();
     return;
   }
   // ================= consumer: one (owned node, element) pair per lane ========================================================
@@ -255,37 +257,35 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
     if (cvalid) consume(q & 1);
     __syncthreads();
   }
-  // ---- epilogue: one equation row at a time through the LDS image -------------------------------------------------------------
+  // ---- epilogue: rows added into the LDS image, image copied out ------------------------------------------------------------
   zero_image();
   uint32_t sl0 = 0, sl1 = 0;
-  int off = 0;
+  int off = 0, len3 = 0;
   if (cvalid) {
     sl0 = pslot[((size_t)w * MAXP + tid) * 2];
     sl1 = pslot[((size_t)w * MAXP + tid) * 2 + 1];
-    off = (int)ntab[(size_t)w * MAXN + na].off;
+    const HostPrepCl::Node nd = ntab[(size_t)w * MAXN + na];
+    off = (int)nd.off;
+    len3 = 3 * (int)nd.len;
   }
-  __syncthreads();
+  lds_barrier();
+  if (cvalid) {
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    if (cvalid) {
+    for (int j = 0; j < 8; j++) {
+      const int s = (int)(((j < 4 ? sl0 : sl1) >> (8 * (j & 3))) & 0xFF);
+      double* p = img + off + 3 * s;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int s = (int)(((j < 4 ? sl0 : sl1) >> (8 * (j & 3))) & 0xFF);
-        double* p = img + off + 3 * s;
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-          __hip_atomic_fetch_add(p + c, acc[j][r][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (r == 0) {
+      for (int r = 0; r < 3; r++)
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          __hip_atomic_fetch_add(lrhs + 3 * na + c, re[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+          __hip_atomic_fetch_add(p + r * len3 + c, acc[j][r][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __syncthreads();
-    copy_out(r);
-    if (r < 2) __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      __hip_atomic_fetch_add(lrhs + 3 * na + c, re[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  lds_barrier();
+  copy_out();
 }
 
 size_t solid_cl_lds_bytes(int cw, int pw, size_t max_row_doubles) {

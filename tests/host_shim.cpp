@@ -191,17 +191,18 @@ int shim_ev_build(int64_t lds_budget, int64_t* stats) {
 // cluster lists of the producer / consumer kernels (rdc_prep_cl.cpp) of the mesh of the last shim_prep_build, and a
 // structural check of them: every (owned node, incident element) pair is listed exactly once, with the local element,
 // local row node, owned-node index and column slots the kernel will use.
-// stats[6] = workgroups, element visits, pairs, largest one-row image (doubles), owned nodes covered, largest cluster
-int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubles, int64_t* stats) {
+// stats[8] = workgroups, element visits, pairs, largest one-row image (doubles), owned nodes covered, largest cluster,
+// 16-lane groups of pairs, groups in which a node occurs twice
+int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubles, int pair_order, int64_t* stats) {
   HostPrepCl::Limits lim;
   stats[5] = 0;
-  lim.max_nodes = max_nodes; lim.max_pairs = max_pairs; lim.max_elems = max_elems; lim.max_row_doubles = max_row_doubles;
+  lim.max_nodes = max_nodes; lim.max_pairs = max_pairs; lim.max_elems = max_elems; lim.max_row_doubles = max_row_doubles; lim.pair_order = pair_order;
   g_err = prep_build_cl(g_prep, g_conn.data(), lim, g_cl);
   if (!g_err.empty()) return 1;
   const HostPrepCl& C = g_cl;
   const int nen = g_prep.nen;
   std::vector<int32_t> npairs_of((size_t)g_prep.n_owned, 0), seen((size_t)g_prep.n_owned, 0);
-  int64_t covered = 0, largest = 0;
+  int64_t covered = 0, largest = 0, groups = 0, groups_twice = 0;
   for (size_t w = 0; w < C.desc.size(); w++) {
     const HostPrepCl::Desc& d = C.desc[w];
     if (d.nown > lim.max_nodes || d.npair > lim.max_pairs || d.nelem > lim.max_elems || (int)d.row_doubles > lim.max_row_doubles) { g_err = "limits"; return 2; }
@@ -212,7 +213,7 @@ int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubl
       const HostPrepCl::Node& nd = C.ntab[w * lim.max_nodes + a];
       if ((int64_t)nd.node >= g_prep.n_owned || seen[nd.node]++) { g_err = "node listed twice"; return 3; }
       if (nd.bptr != (uint32_t)g_prep.bptr[nd.node] || nd.len != g_prep.bptr[nd.node + 1] - g_prep.bptr[nd.node] || nd.off != off) { g_err = "node table"; return 4; }
-      off += (uint32_t)(g_prep.nvar * nd.len);
+      off += (uint32_t)(g_prep.nvar * g_prep.nvar * nd.len);
     }
     if (off != d.row_doubles) { g_err = "row_doubles"; return 5; }
     for (int x = 0; x < lim.max_pairs; x++) {
@@ -229,17 +230,18 @@ int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubl
       }
       npairs_of[n]++;
     }
-    // 16 consecutive pairs hit 16 different nodes when the cluster has that many
-    if (d.nown >= 16)
-      for (int x = 0; x + 16 <= d.npair; x++) {
-        uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        for (int y = x; y < x + 16; y++) {
-          const uint32_t a = (C.pair[w * lim.max_pairs + y] >> 16) & 0xFF;
-          uint64_t& m = a < 64 ? m0 : a < 128 ? m1 : a < 192 ? m2 : m3;
-          if (m & (1ull << (a & 63))) { stats[5] = -1; }
-          m |= 1ull << (a & 63);
-        }
+    // the 16 lanes of an atomic pass: count the groups in which a node occurs twice (statistics only)
+    for (int x = 0; x + 16 <= d.npair; x += 16) {
+      uint64_t m[4] = {0, 0, 0, 0};
+      bool twice = false;
+      for (int y = x; y < x + 16; y++) {
+        const uint32_t a = (C.pair[w * lim.max_pairs + y] >> 16) & 0xFF;
+        if (m[a >> 6] & (1ull << (a & 63))) twice = true;
+        m[a >> 6] |= 1ull << (a & 63);
       }
+      groups++;
+      groups_twice += twice;
+    }
   }
   // incident elements per owned node
   std::vector<int32_t> inc((size_t)g_prep.n_owned, 0);
@@ -247,7 +249,7 @@ int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubl
   for (int64_t n = 0; n < g_prep.n_owned; n++)
     if (inc[n] != npairs_of[n] || seen[n] != 1) { g_err = "pair coverage"; return 10; }
   stats[0] = (int64_t)C.desc.size(); stats[1] = C.n_elem_visits; stats[2] = C.n_pairs; stats[3] = (int64_t)C.max_row_doubles;
-  stats[4] = covered; if (stats[5] != -1) stats[5] = largest;
+  stats[4] = covered; stats[5] = largest; stats[6] = groups; stats[7] = groups_twice;
   return 0;
 }
 

@@ -16,10 +16,12 @@ with AssemblyContext(0) as c:
     c.mesh_upload(8, conn, x, 3)
     c.field_upload(FIELD_UNDEFORMED_XYZ, Xu); c.field_upload(FIELD_ELEM_FIBRE, np.tile([0.0, 0.0, 1.0], (conn.shape[0], 1)))
     c.solid_set_materials(em, mats)
+    sel = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
     for rnd in range(2):
-      for name, opts in (("fused 3+1 waves (default)", {}), ("fused 6+2 waves", {"solid_cl_waves": 62}), ("two-pass", {"solid_kernel": 2}),
-                         ("two-pass, pass 1 without stores", {"solid_kernel": 2, "solid_store": 2})):
-        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31)
+      for idx, (name, opts) in enumerate((("fused 3+1 waves (default)", {}), ("fused 6+2 waves", {"solid_cl_waves": 62}), ("two-pass", {"solid_kernel": 2}),
+                         ("two-pass, pass 1 without stores", {"solid_kernel": 2, "solid_store": 2}), ("fused 3+1, node-distinct pair order", {"solid_cl_order": 0}))):
+        if sel is not None and idx not in sel: continue
+        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31); c.set_option("solid_cl_order", 1)
         for k, v in opts.items(): c.set_option(k, v)
         c.solid_assemble(sp, True); c.synchronize()
         c.timing_enable(True)
