@@ -35,7 +35,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
            const uint32_t* __restrict__ eid, const uint32_t* __restrict__ pair, const uint32_t* __restrict__ pslot,
            const double* __restrict__ Xu, const double* __restrict__ fibre, const int32_t* __restrict__ elem_material,
            const rdc_solid_material* __restrict__ materials, const double pseudo_time, double* __restrict__ val,
-           double* __restrict__ rhs) {
+           double* __restrict__ rhs, const int diag /* timing diagnostics (tools/solid_ab.py), bit mask: 1 = consumers idle, 2 = producers idle, 4 = image not zeroed, 8 = no atomics, 16 = no copy-out, 32 = no element loads */) {
   constexpr int MAXP = CW * 64, MAXE = PW * 64, MAXN = CW * 8, NT = (CW + PW) * 64;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int w = blockIdx.x;
@@ -75,7 +75,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
     const bool plive = e != 0xFFFFFFFFu;
     double X[8][3], XU[8][3];
     double mu = 0.0, lame = 0.0, Kf = 0.0, A[3] = {0.0, 0.0, 0.0}, lam[3] = {1.0, 1.0, 1.0}, rlam = 1.0;
-    if (plive) {
+    if (plive && !(diag & 32)) {
 #pragma unroll
       for (int n = 0; n < 8; n++) {
         const int64_t I = m.conn[(int64_t)e * 8 + n];
@@ -163,17 +163,17 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
       pd[45] = alpha * Jr * W;
       pd[46] = beta * Jr * W;
     };
-    if (plive) produce(0, 0);
+    if (plive && !(diag & 2)) produce(0, 0);
     __syncthreads();
 #pragma unroll 1
     for (int q = 0; q < 8; q++) {   // one point ahead of the consumers
-      if (plive && q + 1 < 8) produce(q + 1, (q + 1) & 1);
+      if (plive && q + 1 < 8 && !(diag & 2)) produce(q + 1, (q + 1) & 1);
       __syncthreads();
     }
-    zero_image();
+    if (!(diag & 4)) zero_image();
     lds_barrier();
     lds_barrier();                  // consumers: atomics
-    copy_out();
+    if (!(diag & 16)) copy_out();
     return;
   }
   // ================= consumer: one (owned node, element) pair per lane ========================================================
@@ -254,11 +254,11 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
   __syncthreads();                  // producers: point 0
 #pragma unroll 1
   for (int q = 0; q < 8; q++) {
-    if (cvalid) consume(q & 1);
+    if (cvalid && !(diag & 1)) consume(q & 1);
     __syncthreads();
   }
   // ---- epilogue: rows added into the LDS image, image copied out ------------------------------------------------------------
-  zero_image();
+  if (!(diag & 4)) zero_image();
   uint32_t sl0 = 0, sl1 = 0;
   int off = 0, len3 = 0;
   if (cvalid) {
@@ -269,7 +269,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
     len3 = 3 * (int)nd.len;
   }
   lds_barrier();
-  if (cvalid) {
+  if (cvalid && !(diag & 8)) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int s = (int)(((j < 4 ? sl0 : sl1) >> (8 * (j & 3))) & 0xFF);
@@ -285,7 +285,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
       __hip_atomic_fetch_add(lrhs + 3 * na + c, re[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   lds_barrier();
-  copy_out();
+  if (!(diag & 16)) copy_out();
 }
 
 size_t solid_cl_lds_bytes(int cw, int pw, size_t max_row_doubles) {
@@ -301,12 +301,12 @@ static hipError_t launch_cl(const SolidArgs& a) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_solid_cl<CW, PW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL((k_solid_cl<CW, PW, true>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, a.cl.desc, a.cl.ntab, a.cl.eid,
-                       a.cl.pair, a.cl.pslot, a.Xu, a.fibre, a.elem_material, a.materials, a.params.pseudo_time, a.val, a.rhs);
+                       a.cl.pair, a.cl.pslot, a.Xu, a.fibre, a.elem_material, a.materials, a.params.pseudo_time, a.val, a.rhs, a.store_mode);
   } else {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_solid_cl<CW, PW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL((k_solid_cl<CW, PW, false>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, a.cl.desc, a.cl.ntab, a.cl.eid,
-                       a.cl.pair, a.cl.pslot, a.Xu, a.fibre, a.elem_material, a.materials, a.params.pseudo_time, a.val, a.rhs);
+                       a.cl.pair, a.cl.pslot, a.Xu, a.fibre, a.elem_material, a.materials, a.params.pseudo_time, a.val, a.rhs, a.store_mode);
   }
   return hipGetLastError();
 }

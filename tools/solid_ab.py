@@ -21,7 +21,7 @@ with AssemblyContext(0) as c:
       for idx, (name, opts) in enumerate((("fused 3+1 waves (default)", {}), ("fused 6+2 waves", {"solid_cl_waves": 62}), ("two-pass", {"solid_kernel": 2}),
                          ("two-pass, pass 1 without stores", {"solid_kernel": 2, "solid_store": 2}), ("fused 3+1, node-distinct pair order", {"solid_cl_order": 0}))):
         if sel is not None and idx not in sel: continue
-        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31); c.set_option("solid_cl_order", 1)
+        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31); c.set_option("solid_cl_order", 1); c.set_option("solid_cl_order", 1)
         for k, v in opts.items(): c.set_option(k, v)
         c.solid_assemble(sp, True); c.synchronize()
         c.timing_enable(True)
