@@ -80,6 +80,7 @@ struct rdc_ctx {
   int solid_cl_waves = 31;   // consumer / producer waves the lists were built for (opt_solid_cl_waves at that time)
   size_t scl_max_row_doubles = 0;
   int scl_n_wg = 0;
+  int opt_hex_kernel = 0;       // HEX8 reaction-diffusion, three unknowns: 0 = producer / consumer cluster kernel (default), 1 = pair kernels (k_rowgather_staged / k_rowgather)
   int opt_solid_cl_order = 1;   // pair order of the cluster lists (rdc_prep_cl.cpp): 1 = element-major over colour-sorted elements, 0 = node-distinct
   int solid_cl_order = 1;
   int opt_solid_cl_waves = 31;  // 31 = 3 consumer + 1 producer waves (two workgroups per CU), 62 = 6 + 2 (one per CU)
@@ -274,6 +275,54 @@ int part1_workgroups(const rdc_ctx* c) {
   return lo;
 }
 
+// cluster lists of the producer / consumer HEX8 kernels (three unknowns: solid system and reaction-diffusion models share
+// them), built on first use.  solid_cl_state: 1 = ready, -1 = not available for this mesh (c->err says why).
+int ensure_cluster_lists(rdc_ctx* c) {
+  int rc;
+  if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != c->opt_solid_cl_order)) c->solid_cl_state = 0;
+  if (c->solid_cl_state != 0) return RDC_OK;
+  const int cw = c->opt_solid_cl_waves / 10, pw = c->opt_solid_cl_waves % 10;
+  HostPrepCl::Limits lim;
+  lim.max_nodes = cw * 8; lim.max_pairs = cw * 64; lim.max_elems = pw * 64;
+  // the LDS image of the cluster's CSR rows overlays the point buffers of the solid kernel (2 x 64 pw records of 49 doubles)
+  lim.max_row_doubles = (int)(2 * pw * 64 * 49) - 3 * cw * 8 - 2;
+  lim.pair_order = c->opt_solid_cl_order;
+  HostPrepCl cl;
+  std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
+  RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl);
+  c->solid_cl_waves = c->opt_solid_cl_waves;
+  c->solid_cl_order = c->opt_solid_cl_order;
+  if (!err.empty()) {
+    c->solid_cl_state = -1;
+    std::snprintf(c->err, sizeof(c->err), "%s", err.c_str());
+    return RDC_OK;
+  }
+  if ((rc = dev_upload(c, c->scl_desc, cl.desc))) return rc;
+  if ((rc = dev_upload(c, c->scl_ntab, cl.ntab))) return rc;
+  if ((rc = dev_upload(c, c->scl_eid, cl.eid))) return rc;
+  if ((rc = dev_upload(c, c->scl_pair, cl.pair))) return rc;
+  if ((rc = dev_upload(c, c->scl_pslot, cl.pslot))) return rc;
+  RDC_HIP(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+  c->scl_max_row_doubles = cl.max_row_doubles;
+  c->scl_n_wg = (int)cl.desc.size();
+  c->solid_cl_state = 1;
+  return RDC_OK;
+}
+
+ClDev cluster_view(const rdc_ctx* c) {
+  ClDev v;
+  v.n_wg = c->scl_n_wg; v.cw = c->solid_cl_waves / 10; v.pw = c->solid_cl_waves % 10;
+  v.desc = (const HostPrepCl::Desc*)c->scl_desc.p;
+  v.ntab = (const HostPrepCl::Node*)c->scl_ntab.p;
+  v.eid = (const uint32_t*)c->scl_eid.p;
+  v.pair = (const uint32_t*)c->scl_pair.p;
+  v.pslot = (const uint32_t*)c->scl_pslot.p;
+  v.max_row_doubles = c->scl_max_row_doubles;
+  return v;
+}
+
 template <class M, class P>
 int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   if (!c) return RDC_ERR_INVALID;
@@ -403,6 +452,11 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     }
   } else {
     c->part1_packed = false;
+  }
+  // HEX8, three unknowns: producer / consumer cluster kernel (whole-mesh assembly only; a two-part call uses the pair kernels)
+  if (a.nen == 8 && M::NV == 3 && c->opt_hex_kernel == 0 && c->opt_part == 0 && a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
+    if ((rc = ensure_cluster_lists(c))) return rc;
+    if (c->solid_cl_state == 1) a.cl = cluster_view(c);
   }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
@@ -539,6 +593,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "solid_kernel")) {
     if (value < 0 || value > 3) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (default), 1 (coloured), 2 (two-pass) or 3 (fused cluster kernel)");
     c->opt_solid_kernel = value;
+  } else if (!std::strcmp(key, "hex_kernel")) {
+    c->opt_hex_kernel = value ? 1 : 0;
   } else if (!std::strcmp(key, "solid_cl_order")) {
     c->opt_solid_cl_order = value ? 1 : 0;
   } else if (!std::strcmp(key, "solid_cl_waves")) {
@@ -848,44 +904,11 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   // kernel choice: the fused cluster kernel serves HEX8 tangent requests; everything else is two-pass (or coloured on request)
   int kernel = c->opt_solid_kernel == 1 ? 1 : 0;
   if ((c->opt_solid_kernel == 0 || c->opt_solid_kernel == 3) && c->prep.nen == 8 && request_jacobian) {
-    if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != c->opt_solid_cl_order)) c->solid_cl_state = 0;
-    if (c->solid_cl_state == 0) {  // one-time: cluster lists
-      const int cw = c->opt_solid_cl_waves / 10, pw = c->opt_solid_cl_waves % 10;
-      HostPrepCl::Limits lim;
-      lim.max_nodes = cw * 8; lim.max_pairs = cw * 64; lim.max_elems = pw * 64;
-      lim.max_row_doubles = (int)(2 * pw * 64 * 49) - 3 * cw * 8 - 2;   // the image overlays the point buffers
-      lim.pair_order = c->opt_solid_cl_order;
-      HostPrepCl cl;
-      std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
-      RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-      RDC_HIP(c, hipStreamSynchronize(c->stream));
-      const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl);
-      c->solid_cl_waves = c->opt_solid_cl_waves;
-      c->solid_cl_order = c->opt_solid_cl_order;
-      if (!err.empty()) {
-        c->solid_cl_state = -1;
-        if (c->opt_solid_kernel == 3) return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: %s", err.c_str());
-      } else {
-        if ((rc = dev_upload(c, c->scl_desc, cl.desc))) return rc;
-        if ((rc = dev_upload(c, c->scl_ntab, cl.ntab))) return rc;
-        if ((rc = dev_upload(c, c->scl_eid, cl.eid))) return rc;
-        if ((rc = dev_upload(c, c->scl_pair, cl.pair))) return rc;
-        if ((rc = dev_upload(c, c->scl_pslot, cl.pslot))) return rc;
-        RDC_HIP(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
-        c->scl_max_row_doubles = cl.max_row_doubles;
-        c->scl_n_wg = (int)cl.desc.size();
-        c->solid_cl_state = 1;
-      }
-    }
+    if ((rc = ensure_cluster_lists(c))) return rc;
+    if (c->solid_cl_state != 1 && c->opt_solid_kernel == 3) return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: %s", c->err);
     if (c->solid_cl_state == 1) {
       kernel = 3;
-      a.cl.n_wg = c->scl_n_wg; a.cl.cw = c->solid_cl_waves / 10; a.cl.pw = c->solid_cl_waves % 10;
-      a.cl.desc = (const HostPrepCl::Desc*)c->scl_desc.p;
-      a.cl.ntab = (const HostPrepCl::Node*)c->scl_ntab.p;
-      a.cl.eid = (const uint32_t*)c->scl_eid.p;
-      a.cl.pair = (const uint32_t*)c->scl_pair.p;
-      a.cl.pslot = (const uint32_t*)c->scl_pslot.p;
-      a.cl.max_row_doubles = c->scl_max_row_doubles;
+      a.cl = cluster_view(c);
     }
   } else if (c->opt_solid_kernel == 3) {
     return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: HEX8 tangent requests only");

@@ -47,6 +47,17 @@ struct EvDev {
   size_t max_out_doubles = 0;
 };
 
+// device view of the cluster lists (HostPrepCl) of the producer / consumer HEX8 kernels (rdc_solid_cl.hip, rdc_hex8_cl_kernel.h)
+struct ClDev {
+  int n_wg = 0, cw = 3, pw = 1;     // consumer / producer waves per workgroup the lists were built for
+  const HostPrepCl::Desc* desc = nullptr;
+  const HostPrepCl::Node* ntab = nullptr;
+  const uint32_t* eid = nullptr;
+  const uint32_t* pair = nullptr;
+  const uint32_t* pslot = nullptr;
+  size_t max_row_doubles = 0;
+};
+
 // ---- kernel launch plumbing -----------------------------------------------------------------
 struct LaunchArgs {
   MeshDev m;
@@ -67,6 +78,7 @@ struct LaunchArgs {
   int opt_occ, opt_ablate, opt_kernel, opt_special, opt_xcd, opt_grid, opt_pf, opt_slim = 0, opt_moments = 1, opt_stagger = 0, opt_ldspad = 0;  // tuning knobs (rdc_set_option)
   Rg2Dev rg2;
   EvDev ev;
+  ClDev cl;              // HEX8, three unknowns: cluster lists (n_wg = 0: not available / not wanted)
   bool use_ev = false;   // element-visit kernel allowed for this call
   int opt_ev_occ = 3;
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)

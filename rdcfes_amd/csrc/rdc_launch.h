@@ -3,6 +3,7 @@
 #ifndef RDC_LAUNCH_H
 #define RDC_LAUNCH_H
 #include "rdc_internal.h"
+#include "rdc_hex8_cl_kernel.h"
 
 namespace rdc {
 
@@ -12,6 +13,10 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
   if (a.strategy == RDC_SCATTER_ROWGATHER) {
     constexpr int BLOCK = 256;
     if (a.n_wg > 0) {
+      if constexpr (NEN == 8 && M::NV == 3) {
+        // producer / consumer cluster kernel (rdc_hex8_cl.h) when the context built its lists
+        if (a.cl.n_wg > 0) return launch_hex8_cl<M, EXP_MODE>(a, k);
+      }
       if constexpr (NEN == 8) {
         // node-staged form when the workgroup's row slice and node table fit 80 KB of LDS (two workgroups per CU)
         constexpr int REC = 3 + M::NV + (M::NAUX > 0 ? M::NAUX : 0);

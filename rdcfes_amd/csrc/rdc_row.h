@@ -168,14 +168,10 @@ RDC_HD void rd_point_accum_row(const RowPoint<M, NEN>& P, double (&acc)[M::NV][N
   }
 }
 
-// ---- contribution of quadrature point q to the row of local node `irow` ------------------------------
-template <class M, int NEN, int EXP_MODE>
-RDC_HD void rd_row_point(const typename M::K& k, const double (&X)[NEN][3], const double (&U)[NEN][M::NV],
-                         const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int q, int irow,
-                         double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV], const double* ED) {
+// ---- accumulation of one quadrature point, all equation rows (P: rd_point_setup, or the point record of rdc_hex8_cl.h) ----
+template <class M, int NEN>
+RDC_HD void rd_point_accum(const RowPoint<M, NEN>& P, double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV]) {
   constexpr int NV = M::NV, NG = M::NG;
-  RowPoint<M, NEN> P;
-  rd_point_setup<M, NEN, EXP_MODE>(k, X, U, AX, q, irow, ED, P);
 #pragma unroll
   for (int a = 0; a < NV; a++) {
     double r = P.c.R[a] * P.Ni;
@@ -213,6 +209,16 @@ RDC_HD void rd_row_point(const typename M::K& k, const double (&X)[NEN][3], cons
         acc[a][b][j] = v;
       }
   }
+}
+
+// ---- contribution of quadrature point q to the row of local node `irow` ------------------------------
+template <class M, int NEN, int EXP_MODE>
+RDC_HD void rd_row_point(const typename M::K& k, const double (&X)[NEN][3], const double (&U)[NEN][M::NV],
+                         const double (&AX)[NEN][M::NAUX > 0 ? M::NAUX : 1], int q, int irow,
+                         double (&acc)[M::NV][M::NV][NEN], double (&fe)[M::NV], const double* ED) {
+  RowPoint<M, NEN> P;
+  rd_point_setup<M, NEN, EXP_MODE>(k, X, U, AX, q, irow, ED, P);
+  rd_point_accum<M, NEN>(P, acc, fe);
 }
 
 // ---- one row (local node `irow`) of Ke and Fe over all quadrature points ------------------

@@ -3,16 +3,7 @@
 #define RDC_SOLID_H
 #include "rdc_internal.h"
 namespace rdc {
-// device view of the cluster lists (HostPrepCl) of the fused HEX8 kernel (rdc_solid_cl.hip)
-struct SolidClDev {
-  int n_wg = 0, cw = 3, pw = 1;     // consumer / producer waves per workgroup the lists were built for
-  const HostPrepCl::Desc* desc = nullptr;
-  const HostPrepCl::Node* ntab = nullptr;
-  const uint32_t* eid = nullptr;
-  const uint32_t* pair = nullptr;
-  const uint32_t* pslot = nullptr;
-  size_t max_row_doubles = 0;
-};
+using SolidClDev = ClDev;   // cluster lists of the fused HEX8 kernel (rdc_solid_cl.hip)
 struct SolidArgs {
   MeshDev m;
   int nen;

@@ -10,6 +10,7 @@
 #include "../rdcfes_amd/csrc/rdc_tet4_fast.h"
 #include "../rdcfes_amd/csrc/rdc_tet4_pihna_moments.h"
 #include "../rdcfes_amd/csrc/rdc_tet4_ev.h"
+#include "../rdcfes_amd/csrc/rdc_hex8_cl.h"
 
 using namespace rdc;
 
@@ -120,6 +121,61 @@ struct EvHostSink {
   void mom(int m, int i, int j, double v) { M[m * ev::NBP + blk[i][j]] += v; }
   void rhs(int a, int i, double v) { R[a * ev::MAXN + nloc[i]] += v; }
 };
+
+
+// k_hex8_cl replayed on the host from the cluster lists of the last shim_cl_build and the SAME record functions
+// (hex8_cl_produce / hex8_cl_consume): per cluster the point records of its elements, then per pair the row over the eight
+// points, added into the CSR rows at the slots of the pair list.  val / rhs: the caller pre-fills NaN; covered entries are
+// first zeroed here (every owned row belongs to exactly one cluster).
+template <class M, class P>
+int cl_replay(const P* p, const double* xyz, const double* u, const double* aux, const double* elem, double* val, double* rhs) {
+  constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
+  using R = Hex8Rec<M>;
+  if (!g_cl.ok || g_prep.nen != 8 || g_prep.nvar != NV) return 1;
+  const typename M::K k = M::derive(*p);
+  const bool fastexp = exp_mode_of(M::exponent(k)) == M::FAST_EXP_MODE;
+  const HostPrepCl& C = g_cl;
+  std::vector<double> rec;
+  for (size_t w = 0; w < C.desc.size(); w++) {
+    const HostPrepCl::Desc& d = C.desc[w];
+    rec.assign((size_t)d.nelem * 8 * R::STRIDE, 0.0);
+    for (int le = 0; le < d.nelem; le++) {
+      const uint32_t e = C.eid[w * C.lim.max_elems + le];
+      double X[8][3], U[8][NV], AX[8][NA];
+      for (int n = 0; n < 8; n++) {
+        const uint32_t I = g_conn[(size_t)e * 8 + n];
+        for (int c = 0; c < 3; c++) X[n][c] = xyz[3 * (size_t)I + c];
+        for (int v = 0; v < NV; v++) U[n][v] = u[NV * (size_t)I + v];
+        for (int v = 0; v < NA; v++) AX[n][v] = (M::NAUX > 0 && aux) ? aux[(size_t)M::NAUX * I + (v % (M::NAUX > 0 ? M::NAUX : 1))] : 0.0;
+      }
+      const double* ED = M::NELEM > 0 ? elem + (size_t)e * M::NELEM : nullptr;
+      for (int q = 0; q < 8; q++) {
+        double* r = &rec[((size_t)le * 8 + q) * R::STRIDE];
+        if (fastexp) hex8_cl_produce<M, M::FAST_EXP_MODE>(k, X, U, AX, ED, q, r); else hex8_cl_produce<M, 0>(k, X, U, AX, ED, q, r);
+      }
+    }
+    for (int a = 0; a < d.nown; a++) {
+      const HostPrepCl::Node& nd = C.ntab[w * C.lim.max_nodes + a];
+      for (int x = 0; x < NV * NV * (int)nd.len; x++) val[(size_t)NV * NV * nd.bptr + x] = 0.0;
+      for (int v = 0; v < NV; v++) rhs[(size_t)NV * nd.node + v] = 0.0;
+    }
+    for (int x = 0; x < d.npair; x++) {
+      const uint32_t pr = C.pair[w * C.lim.max_pairs + x];
+      const uint32_t le = pr & 0xFF, li = (pr >> 8) & 0xFF, a = (pr >> 16) & 0xFF;
+      double acc[NV][NV][8], fe[NV];
+      rd_row_zero<M, 8>(acc, fe);
+      for (int q = 0; q < 8; q++) hex8_cl_consume<M>(k, &rec[((size_t)le * 8 + q) * R::STRIDE], q, (int)li, acc, fe);
+      const HostPrepCl::Node& nd = C.ntab[w * C.lim.max_nodes + a];
+      for (int j = 0; j < 8; j++) {
+        const uint32_t sl = (C.pslot[(w * C.lim.max_pairs + x) * 2 + j / 4] >> (8 * (j % 4))) & 0xFF;
+        for (int aa = 0; aa < NV; aa++)
+          for (int b = 0; b < NV; b++) val[(size_t)NV * NV * nd.bptr + (size_t)aa * NV * nd.len + NV * sl + b] += acc[aa][b][j];
+      }
+      for (int v = 0; v < NV; v++) rhs[(size_t)NV * nd.node + v] += fe[v];
+    }
+  }
+  return 0;
+}
 
 }  // namespace
 
@@ -251,6 +307,23 @@ int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubl
   stats[0] = (int64_t)C.desc.size(); stats[1] = C.n_elem_visits; stats[2] = C.n_pairs; stats[3] = (int64_t)C.max_row_doubles;
   stats[4] = covered; stats[5] = largest; stats[6] = groups; stats[7] = groups_twice;
   return 0;
+}
+
+// model: 1 RIPF, 2 HCC, 4 ADPM, 7 RIPF reduced, 8 HCC mass only, 9 ADPM decay only (as shim_row)
+int shim_cl_assemble(int model, const void* params, const double* xyz, const double* u, const double* aux, const double* elem,
+                     double* val, double* rhs) {
+  switch (model) {
+    case 1: return cl_replay<Ripf>((const rdc_ripf_params*)params, xyz, u, aux, elem, val, rhs);
+    case 2: return cl_replay<Hcc>((const rdc_hcc_params*)params, xyz, u, aux, elem, val, rhs);
+    case 4: return cl_replay<Adpm>((const rdc_adpm_params*)params, xyz, u, aux, elem, val, rhs);
+    case 7: if (!RipfReduced::applies(*(const rdc_ripf_params*)params)) return 3;
+            return cl_replay<RipfReduced>((const rdc_ripf_params*)params, xyz, u, aux, elem, val, rhs);
+    case 8: if (!HccMassOnly::applies(*(const rdc_hcc_params*)params)) return 3;
+            return cl_replay<HccMassOnly>((const rdc_hcc_params*)params, xyz, u, aux, elem, val, rhs);
+    case 9: if (!AdpmDecayOnly::applies(*(const rdc_adpm_params*)params)) return 3;
+            return cl_replay<AdpmDecayOnly>((const rdc_adpm_params*)params, xyz, u, aux, elem, val, rhs);
+  }
+  return 2;
 }
 
 // The kernel k_tet4_ev replayed on the host, phase by phase and workgroup by workgroup, from the SAME lists and the

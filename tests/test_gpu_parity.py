@@ -35,9 +35,11 @@ def _inputs(model, nen, n, order="random", variant="full"):
     return conn, xyz, u, aux, p
 
 
-def _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, n_owned=None):
+def _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, n_owned=None, options=()):
     nv = 5 if model == 0 else 3
     with AssemblyContext(0) as ctx:
+        for key, value in options:
+            ctx.set_option(key, value)
         ctx.mesh_upload(nen, conn, xyz, nv, n_owned=n_owned)
         ctx.set_scatter(strategy)
         ctx.set_kernel_variant(variant)
@@ -75,6 +77,21 @@ def test_parity_small_mesh(oracle, model, nen, strategy, variant, pvariant):
     assert rel(val, val0) < TOL
     x = np.random.default_rng(1).standard_normal(xyz.shape[0] * nv)
     assert rel(csr_matvec(rp, col, val, x), csr_matvec(rp0, col0, val0, x)) < TOL
+    if nen == 8 and nv == 3 and strategy == SCATTER_ROWGATHER:
+        # the default above is the producer / consumer cluster kernel (rdc_hex8_cl.h); the pair kernels stay covered
+        _, _, val, rhs = _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, options=(("hex_kernel", 1),))
+        assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
+def test_hex8_cluster_kernel_on_a_ghosted_partition(oracle):
+    """the HEX8 cluster kernel with ghost nodes: rows only for the owned nodes, every (owned node, element) pair once"""
+    conn, xyz, u, aux, p = _inputs(2, 8, 7, variant="full")
+    n_owned = int(0.55 * xyz.shape[0])
+    conn = conn[(conn < n_owned).any(axis=1)]
+    rp0, col0, val0, rhs0 = oracle.assemble(2, 8, conn, xyz, 3, p, u_old=u, n_owned=n_owned)
+    rp, col, val, rhs = _gpu_assemble(2, 8, conn, xyz, u, None, p, SCATTER_ROWGATHER, VARIANT_GENERIC, n_owned=n_owned)
+    np.testing.assert_array_equal(rp, rp0)
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
 
 
 @pytest.mark.parametrize("strategy", [SCATTER_COLOURED, SCATTER_ROWGATHER])

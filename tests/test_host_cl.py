@@ -52,3 +52,65 @@ def test_cluster_lists_tiny_limits(shim):
     conn, xyz = synth.hex_mesh(4, jitter=0.0)
     st = _build(shim, 8, conn, xyz.shape[0], xyz.shape[0], (1, 8, 8, 243))
     assert st["n_wg"] == xyz.shape[0] and st["largest"] == 1
+
+
+# ---- the HEX8 reaction-diffusion cluster kernel (rdc_hex8_cl.h) replayed on the host against the oracle ----------------------
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _replay(shim, model, p, conn, xyz, u, aux, tracts, n_owned, lim=(24, 192, 64, 6198), order=1):
+    _build(shim, 8, conn, xyz.shape[0], n_owned, lim, order)
+    bptr = np.empty(shim.shim_prep_size(0), dtype=np.int64)
+    shim.shim_prep_copy(0, bptr.ctypes.data_as(C.c_void_p))
+    val = np.full(9 * bptr[n_owned], np.nan)
+    rhs = np.full(3 * n_owned, np.nan)
+    dp = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (xyz, u, aux, tracts)]
+    ptr = [a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None for a in keep]
+    rc = shim.shim_cl_assemble(model, C.byref(p), ptr[0], ptr[1], ptr[2], ptr[3], dp(val) if False else val.ctypes.data_as(C.POINTER(C.c_double)),
+                               rhs.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0, rc
+    return val, rhs
+
+
+@pytest.mark.parametrize("order", ["lex", "random"])
+@pytest.mark.parametrize("params", ["full", "shipped"])
+def test_hex8_cluster_replay_hcc(oracle, shim, order, params):
+    from rdcfes_amd import hcc_params_from_dict
+    conn, xyz = synth.hex_mesh(6, jitter=0.15, order=order)
+    u = synth.hcc_fields(xyz)
+    p = hcc_params_from_dict(synth.hcc_param_dict(params))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_HCC, 8, conn, xyz, 3, p, u_old=u)
+    val, rhs = _replay(shim, 2, p, conn, xyz, u, None, None, xyz.shape[0])
+    assert np.isfinite(val).all() and np.isfinite(rhs).all()
+    assert _rel(val, val0) < 1e-10 and _rel(rhs, rhs0) < 1e-10
+    if params == "shipped":      # every rate zero: the mass-only instantiation gives the same numbers
+        val2, rhs2 = _replay(shim, 8, p, conn, xyz, u, None, None, xyz.shape[0])
+        assert _rel(val2, val0) < 1e-10 and _rel(rhs2, rhs0) < 1e-10
+
+
+def test_hex8_cluster_replay_ripf_and_adpm(oracle, shim):
+    from rdcfes_amd import adpm_params_from_dict, ripf_params_from_dict
+    conn, xyz = synth.hex_mesh(5, jitter=0.15, order="random")
+    u, aux = synth.ripf_fields(xyz)
+    p = ripf_params_from_dict(synth.ripf_param_dict("full"))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_RIPF, 8, conn, xyz, 3, p, u_old=u, aux=aux)
+    val, rhs = _replay(shim, 1, p, conn, xyz, u, aux, None, xyz.shape[0])
+    assert _rel(val, val0) < 1e-10 and _rel(rhs, rhs0) < 1e-10
+    u, tracts = synth.adpm_fields(xyz, conn.shape[0])
+    p = adpm_params_from_dict(synth.adpm_param_dict("full"), time=3.0)
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_ADPM, 8, conn, xyz, 3, p, u_old=u, elem_fibre=tracts)
+    val, rhs = _replay(shim, 4, p, conn, xyz, u, None, tracts, xyz.shape[0])
+    assert _rel(val, val0) < 1e-10 and _rel(rhs, rhs0) < 1e-10
+
+
+def test_hex8_cluster_replay_on_a_ghosted_partition(oracle, shim):
+    from rdcfes_amd import hcc_params_from_dict
+    conn, xyz = synth.hex_mesh(6, jitter=0.1, order="random")
+    n_owned = int(0.55 * xyz.shape[0])
+    u = synth.hcc_fields(xyz)
+    p = hcc_params_from_dict(synth.hcc_param_dict("full"))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_HCC, 8, conn, xyz, 3, p, u_old=u, n_owned=n_owned)
+    val, rhs = _replay(shim, 2, p, conn, xyz, u, None, None, n_owned)
+    assert _rel(val, val0) < 1e-10 and _rel(rhs, rhs0) < 1e-10
