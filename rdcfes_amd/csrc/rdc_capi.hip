@@ -80,8 +80,8 @@ struct rdc_ctx {
   int solid_cl_waves = 31;   // consumer / producer waves the lists were built for (opt_solid_cl_waves at that time)
   size_t scl_max_row_doubles = 0;
   int scl_n_wg = 0;
-  int opt_hex_kernel = 0;       // HEX8 reaction-diffusion, three unknowns: 0 = producer / consumer cluster kernel (default), 1 = pair kernels (k_rowgather_staged / k_rowgather)
-  int opt_solid_cl_order = 1;   // pair order of the cluster lists (rdc_prep_cl.cpp): 1 = element-major over colour-sorted elements, 0 = node-distinct
+  int opt_hex_kernel = 0;       // HEX8 reaction-diffusion, three unknowns: 0 = producer / consumer cluster kernel (default), 1 = pair kernels (k_rowgather_staged / k_rowgather), 2 = persistent form of the cluster kernel
+  int opt_solid_cl_order = -1;  // pair order of the cluster lists (rdc_prep_cl.cpp): 1 = element-major over colour-sorted elements, 0 = node-distinct, -1 = by first use (solid: 1, reaction-diffusion: 0)
   int solid_cl_order = 1;
   int opt_solid_cl_waves = 31;  // 31 = 3 consumer + 1 producer waves (two workgroups per CU), 62 = 6 + 2 (one per CU)
   int opt_solid_kernel = 0;  // 0 = default: fused cluster kernel for HEX8 tangent requests, two-pass otherwise; 1 = coloured read-modify-write; 2 = two-pass; 3 = fused (error if unavailable)
@@ -95,6 +95,7 @@ struct rdc_ctx {
   std::vector<hipEvent_t> ev;   // pairs (start, stop), one pair per timed assemble call
   size_t ev_used = 0;           // events handed out since the last rdc_timing_sum_ms / enable
   size_t max_lds = 64 * 1024;
+  int n_cu = 256;
 };
 
 namespace {
@@ -277,23 +278,24 @@ int part1_workgroups(const rdc_ctx* c) {
 
 // cluster lists of the producer / consumer HEX8 kernels (three unknowns: solid system and reaction-diffusion models share
 // them), built on first use.  solid_cl_state: 1 = ready, -1 = not available for this mesh (c->err says why).
-int ensure_cluster_lists(rdc_ctx* c) {
+int ensure_cluster_lists(rdc_ctx* c, int order_of_caller) {
   int rc;
-  if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != c->opt_solid_cl_order)) c->solid_cl_state = 0;
+  const int want_order = c->opt_solid_cl_order < 0 ? (c->solid_cl_state == 1 ? c->solid_cl_order : order_of_caller) : c->opt_solid_cl_order;
+  if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != want_order)) c->solid_cl_state = 0;
   if (c->solid_cl_state != 0) return RDC_OK;
   const int cw = c->opt_solid_cl_waves / 10, pw = c->opt_solid_cl_waves % 10;
   HostPrepCl::Limits lim;
   lim.max_nodes = cw * 8; lim.max_pairs = cw * 64; lim.max_elems = pw * 64;
   // the LDS image of the cluster's CSR rows overlays the point buffers of the solid kernel (2 x 64 pw records of 49 doubles)
   lim.max_row_doubles = (int)(2 * pw * 64 * 49) - 3 * cw * 8 - 2;
-  lim.pair_order = c->opt_solid_cl_order;
+  lim.pair_order = want_order;
   HostPrepCl cl;
   std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
   RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   RDC_HIP(c, hipStreamSynchronize(c->stream));
   const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl);
   c->solid_cl_waves = c->opt_solid_cl_waves;
-  c->solid_cl_order = c->opt_solid_cl_order;
+  c->solid_cl_order = want_order;
   if (!err.empty()) {
     c->solid_cl_state = -1;
     std::snprintf(c->err, sizeof(c->err), "%s", err.c_str());
@@ -454,9 +456,12 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     c->part1_packed = false;
   }
   // HEX8, three unknowns: producer / consumer cluster kernel (whole-mesh assembly only; a two-part call uses the pair kernels)
-  if (a.nen == 8 && M::NV == 3 && c->opt_hex_kernel == 0 && c->opt_part == 0 && a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
-    if ((rc = ensure_cluster_lists(c))) return rc;
-    if (c->solid_cl_state == 1) a.cl = cluster_view(c);
+  if (a.nen == 8 && M::NV == 3 && c->opt_hex_kernel != 1 && c->opt_part == 0 && a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
+    if ((rc = ensure_cluster_lists(c, 0))) return rc;
+    if (c->solid_cl_state == 1) {
+      a.cl = cluster_view(c);
+      a.cl.grid = c->opt_hex_kernel == 2 ? 2 * c->n_cu : 0;   // persistent form: the workgroups resident at once
+    }
   }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
@@ -513,6 +518,7 @@ int rdc_ctx_create(int device_ordinal, rdc_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.sharedMemPerBlock > 0)
     c->max_lds = prop.sharedMemPerBlock;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   *out = c;
   return RDC_OK;
 }
@@ -594,9 +600,10 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     if (value < 0 || value > 3) return fail(c, RDC_ERR_INVALID, "solid_kernel must be 0 (default), 1 (coloured), 2 (two-pass) or 3 (fused cluster kernel)");
     c->opt_solid_kernel = value;
   } else if (!std::strcmp(key, "hex_kernel")) {
-    c->opt_hex_kernel = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(c, RDC_ERR_INVALID, "hex_kernel must be 0 (cluster kernel), 1 (pair kernels) or 2 (persistent cluster kernel)");
+    c->opt_hex_kernel = value;
   } else if (!std::strcmp(key, "solid_cl_order")) {
-    c->opt_solid_cl_order = value ? 1 : 0;
+    c->opt_solid_cl_order = value < 0 ? -1 : (value ? 1 : 0);
   } else if (!std::strcmp(key, "solid_cl_waves")) {
     if (value != 31 && value != 62) return fail(c, RDC_ERR_INVALID, "solid_cl_waves must be 31 (3 consumer + 1 producer waves) or 62");
     c->opt_solid_cl_waves = value;
@@ -904,7 +911,7 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   // kernel choice: the fused cluster kernel serves HEX8 tangent requests; everything else is two-pass (or coloured on request)
   int kernel = c->opt_solid_kernel == 1 ? 1 : 0;
   if ((c->opt_solid_kernel == 0 || c->opt_solid_kernel == 3) && c->prep.nen == 8 && request_jacobian) {
-    if ((rc = ensure_cluster_lists(c))) return rc;
+    if ((rc = ensure_cluster_lists(c, 1))) return rc;
     if (c->solid_cl_state != 1 && c->opt_solid_kernel == 3) return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: %s", c->err);
     if (c->solid_cl_state == 1) {
       kernel = 3;

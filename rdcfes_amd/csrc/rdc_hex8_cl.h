@@ -7,10 +7,11 @@
 //   * a workgroup owns a cluster of <= CW * 8 owned nodes (rdc_prep_cl.cpp);
 //   * PW producer waves: one lane per element touching the cluster, whose coordinates and unknowns stay in its registers;
 //     per quadrature point it evaluates the POINT RECORD once: S = Ji Ji^T (6), JxW, h_g = Ji grad f_g for the model's
-//     gradient fields (3 each), and the model's point state M::Pt (old solution, crowding function, ...), through LDS;
+//     gradient fields (3 each), and the interpolated unknowns / aux fields, through LDS;
 //   * CW consumer waves: one lane per pair; per point it reads the record, forms what depends on its row node
-//     (b_i = S dN_i, grad phi_j . grad phi_i = dN_j . b_i, grad f_g . grad phi_i = h_g . dN_i), evaluates M::coef and
-//     accumulates with the generic evaluator's own accumulation (rd_point_accum): NV^2 x 8 accumulators;
+//     (b_i = S dN_i, grad phi_j . grad phi_i = dN_j . b_i, grad f_g . grad phi_i = h_g . dN_i), evaluates M::point and
+//     M::coef (cheap next to the geometry; on the producer they made its instruction stream the longest of the
+//     workgroup) and accumulates with the generic evaluator's own accumulation (rd_point_accum): NV^2 x 8 accumulators;
 //   * epilogue: rows added into an LDS image of the cluster's CSR rows (ds_add_f64), image copied out in runs.
 // The record functions are host + device so that the CPU suite replays the kernel from the same lists (tests/host_shim.cpp).
 #ifndef RDC_HEX8_CL_H
@@ -21,14 +22,13 @@ namespace rdc {
 
 template <class M>
 struct Hex8Rec {
-  static constexpr int NPT = (int)(sizeof(typename M::Pt) / sizeof(double));
-  static constexpr int HG = 7, PT = 7 + 3 * M::NG, N = PT + NPT;
+  static constexpr int NA = (M::NAUX > 0 ? M::NAUX : 0);
+  static constexpr int HG = 7, UQ = 7 + 3 * M::NG, AQ = UQ + M::NV, N = AQ + NA;
   static constexpr int STRIDE = N | 1;   // odd: the records of 32 consecutive elements start in 32 different double-banks
-  static_assert(sizeof(typename M::Pt) % sizeof(double) == 0, "point state must be made of doubles");
 };
 
 // point record of element (X, U, AX, ED) at quadrature point q (follows rd_point_setup, HEX8 reference-gradient branch)
-template <class M, int EXP_MODE>
+template <class M>
 RDC_HD void hex8_cl_produce(const typename M::K& k, const double (&X)[8][3], const double (&U)[8][M::NV],
                             const double (&AX)[8][M::NAUX > 0 ? M::NAUX : 1], const double* ED, int q, double* rec) {
   constexpr int NV = M::NV, NG = M::NG, NA = (M::NAUX > 0 ? M::NAUX : 1);
@@ -87,14 +87,14 @@ RDC_HD void hex8_cl_produce(const typename M::K& k, const double (&X)[8][3], con
   for (int g = 0; g < NG; g++)
 #pragma unroll
     for (int c = 0; c < 3; c++) rec[R::HG + 3 * g + c] = Ji[c][0] * GF[g][0] + Ji[c][1] * GF[g][1] + Ji[c][2] * GF[g][2];
-  union { typename M::Pt pt; double w[R::NPT]; } s;
-  M::template point<EXP_MODE>(k, uq, aq, s.pt);
 #pragma unroll
-  for (int x = 0; x < R::NPT; x++) rec[R::PT + x] = s.w[x];
+  for (int v = 0; v < NV; v++) rec[R::UQ + v] = uq[v];
+#pragma unroll
+  for (int v = 0; v < R::NA; v++) rec[R::AQ + v] = aq[v];
 }
 
 // contribution of the point whose record is `rec` to the row of local node irow
-template <class M>
+template <class M, int EXP_MODE>
 RDC_HD void hex8_cl_consume(const typename M::K& k, const double* rec, int q, int irow, double (&acc)[M::NV][M::NV][8],
                             double (&fe)[M::NV]) {
   constexpr int NG = M::NG;
@@ -119,10 +119,14 @@ RDC_HD void hex8_cl_consume(const typename M::K& k, const double* rec, int q, in
 #pragma unroll
   for (int g = 0; g < NG; g++)
     P.gi[g] = rec[R::HG + 3 * g] * dNi[0] + rec[R::HG + 3 * g + 1] * dNi[1] + rec[R::HG + 3 * g + 2] * dNi[2];
-  union { typename M::Pt pt; double w[R::NPT]; } s;
+  double uq[M::NV], aq[M::NAUX > 0 ? M::NAUX : 1] = {0.0};
 #pragma unroll
-  for (int x = 0; x < R::NPT; x++) s.w[x] = rec[R::PT + x];
-  M::coef(k, s.pt, P.c);
+  for (int v = 0; v < M::NV; v++) uq[v] = rec[R::UQ + v];
+#pragma unroll
+  for (int v = 0; v < R::NA; v++) aq[v] = rec[R::AQ + v];
+  typename M::Pt pt;
+  M::template point<EXP_MODE>(k, uq, aq, pt);
+  M::coef(k, pt, P.c);
   rd_point_accum<M, 8>(P, acc, fe);
 }
 

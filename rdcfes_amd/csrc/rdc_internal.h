@@ -56,6 +56,7 @@ struct ClDev {
   const uint32_t* pair = nullptr;
   const uint32_t* pslot = nullptr;
   size_t max_row_doubles = 0;
+  int grid = 0;                     // persistent workgroups to launch (0 = one workgroup per cluster)
 };
 
 // ---- kernel launch plumbing -----------------------------------------------------------------

@@ -151,7 +151,7 @@ int cl_replay(const P* p, const double* xyz, const double* u, const double* aux,
       const double* ED = M::NELEM > 0 ? elem + (size_t)e * M::NELEM : nullptr;
       for (int q = 0; q < 8; q++) {
         double* r = &rec[((size_t)le * 8 + q) * R::STRIDE];
-        if (fastexp) hex8_cl_produce<M, M::FAST_EXP_MODE>(k, X, U, AX, ED, q, r); else hex8_cl_produce<M, 0>(k, X, U, AX, ED, q, r);
+        hex8_cl_produce<M>(k, X, U, AX, ED, q, r);
       }
     }
     for (int a = 0; a < d.nown; a++) {
@@ -164,7 +164,10 @@ int cl_replay(const P* p, const double* xyz, const double* u, const double* aux,
       const uint32_t le = pr & 0xFF, li = (pr >> 8) & 0xFF, a = (pr >> 16) & 0xFF;
       double acc[NV][NV][8], fe[NV];
       rd_row_zero<M, 8>(acc, fe);
-      for (int q = 0; q < 8; q++) hex8_cl_consume<M>(k, &rec[((size_t)le * 8 + q) * R::STRIDE], q, (int)li, acc, fe);
+      for (int q = 0; q < 8; q++) {
+        const double* r = &rec[((size_t)le * 8 + q) * R::STRIDE];
+        if (fastexp) hex8_cl_consume<M, M::FAST_EXP_MODE>(k, r, q, (int)li, acc, fe); else hex8_cl_consume<M, 0>(k, r, q, (int)li, acc, fe);
+      }
       const HostPrepCl::Node& nd = C.ntab[w * C.lim.max_nodes + a];
       for (int j = 0; j < 8; j++) {
         const uint32_t sl = (C.pslot[(w * C.lim.max_pairs + x) * 2 + j / 4] >> (8 * (j % 4))) & 0xFF;

@@ -78,9 +78,11 @@ def test_parity_small_mesh(oracle, model, nen, strategy, variant, pvariant):
     x = np.random.default_rng(1).standard_normal(xyz.shape[0] * nv)
     assert rel(csr_matvec(rp, col, val, x), csr_matvec(rp0, col0, val0, x)) < TOL
     if nen == 8 and nv == 3 and strategy == SCATTER_ROWGATHER:
-        # the default above is the producer / consumer cluster kernel (rdc_hex8_cl.h); the pair kernels stay covered
-        _, _, val, rhs = _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, options=(("hex_kernel", 1),))
-        assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+        # the default above is the producer / consumer cluster kernel (rdc_hex8_cl.h); its persistent form, the other pair order
+        # of the cluster lists and the pair kernels stay covered
+        for options in ((("hex_kernel", 2),), (("solid_cl_order", 1),), (("hex_kernel", 1),)):
+            _, _, val, rhs = _gpu_assemble(model, nen, conn, xyz, u, aux, p, strategy, variant, options=options)
+            assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL, options
 
 
 def test_hex8_cluster_kernel_on_a_ghosted_partition(oracle):

@@ -18,9 +18,10 @@ cases = {
     "proteas": (5, proteas_params_from_dict(synth.proteas_param_dict("full")), *synth.proteas_fields(xyz), None, "assemble_proteas"),
 }
 for name, (nv, p, u, aux, ed, fn) in cases.items():
-    for staged in (-1, 2, 0):   # -1 = cluster kernel (default for three unknowns), 2 = force the node-staged pair kernel, 0 = registers-resident
+    for staged in (-1, -2, 2, 0):   # -1 = cluster kernel (default for three unknowns), -2 = its persistent form, 2 = force the node-staged pair kernel, 0 = registers-resident
+        if staged < 0 and nv != 3: continue
         with AssemblyContext(0) as c:
-            c.set_option("hex_kernel", 0 if staged < 0 else 1)
+            c.set_option("hex_kernel", {-1: 0, -2: 2}.get(staged, 1))
             c.set_option("staged", max(staged, 0))
             c.mesh_upload(8, conn, xyz, nv)
             c.field_upload(FIELD_OLD_SOLUTION, u)
