@@ -101,6 +101,20 @@ def time_config(name, nen, conn, xyz, nvar, setup, call, n_in, solid=False, reps
            "host_prep_s": round(prep_s, 2)}
     if note:
         out["note"] = note
+    # HBM traffic and FP64 rate of this configuration's kernels from the committed counter passes (profiles/pmc_cfg5.json),
+    # only when they were taken from the kernel sources built now
+    try:
+        from rdcfes_amd import build as B
+        t = json.loads((ROOT / "profiles" / "pmc_cfg5.json").read_text())
+        if t.get("source_hash") == B.source_hash():
+            for key, v in t["kernels"].items():
+                if name.startswith(key):
+                    out["traffic"] = int(v["hbm_bytes_per_launch"])
+                    out["fp64_tflops"] = v["fp64_flop_per_launch"] / (ms * 1e-3) / 1e12
+                    out["fp64_frac"] = out["fp64_tflops"] / FP64_PEAK_TFLOPS
+                    out["profile_kernel"] = v["kernel"]
+    except Exception:
+        pass
     return out
 
 

@@ -97,7 +97,8 @@ for w in which:
         def setup(c):
             c.field_upload(FIELD_UNDEFORMED_XYZ, Xu); c.field_upload(FIELD_ELEM_FIBRE, np.tile([0.0, 0.0, 1.0], (conn.shape[0], 1)))
             c.solid_set_materials(em, mats); c.solid_set_sides(se0, ss0, sd)
-        for sk, sg, ss in (((0, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 0)) if conn.shape[0] <= 300000 else ((0, 0, 0), (0, 1, 0), (0, 0, 1))):
+        # solid_kernel: 0 = default (fused cluster kernel for HEX8 tangents, else two-pass), 2 = two-pass, 1 = coloured
+        for sk, sg, ss in (((0, 0, 0), (2, 0, 0), (2, 1, 0), (2, 0, 1), (1, 0, 0)) if conn.shape[0] <= 300000 else ((0, 0, 0), (2, 0, 0))):
             o = (("solid_kernel", sk), ("solid_gather", sg), ("solid_split", ss))
             run(f"SOLID {'TET4 K' if tet else 'HEX8 H'}({n}) residual+Jacobian, solid_kernel={sk} gather={sg} split={ss}", nen, conn, x, 3, setup,
                 lambda c: c.solid_assemble(sp, True), 1, reps=6, n_in=0, solid=True, opts=o)
