@@ -51,7 +51,7 @@ struct rdc_ctx {
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
   HostPrepEv prep_ev;          // element-visit lists (PIHNA TET4, shipped pattern); .ok = available
-  DevBuf ev_desc, ev_nlist, ev_vloc, ev_vslot, ev_ntab, ev_perm;
+  DevBuf ev_desc, ev_nlist, ev_vloc, ev_vslot, ev_ntab, ev_bpart, ev_perm;
   int64_t ev_perm_interior = -2;   // "interior_nodes" value the uploaded workgroup order was built for
   int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
@@ -407,6 +407,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.ev.vloc = (const uint32_t*)c->ev_vloc.p;
     a.ev.vslot = (const uint32_t*)c->ev_vslot.p;
     a.ev.ntab = (const HostPrepEv::Node*)c->ev_ntab.p;
+    a.ev.bpart = (const uint8_t*)c->ev_bpart.p;
     a.ev.nls = c->prep_ev.nls;
     a.ev.max_out_doubles = c->prep_ev.max_out_doubles;
   }
@@ -532,7 +533,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg4_wgntab, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
                    &c->scl_desc, &c->scl_ntab, &c->scl_eid, &c->scl_pair, &c->scl_pslot, &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot,
-                   &c->ev_desc, &c->ev_nlist, &c->ev_vloc, &c->ev_vslot, &c->ev_ntab, &c->ev_perm};
+                   &c->ev_desc, &c->ev_nlist, &c->ev_vloc, &c->ev_vslot, &c->ev_ntab, &c->ev_bpart, &c->ev_perm};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -680,6 +681,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
       if ((rc = dev_upload(c, c->ev_vloc, c->prep_ev.vloc))) return rc;
       if ((rc = dev_upload(c, c->ev_vslot, c->prep_ev.vslot))) return rc;
       if ((rc = dev_upload(c, c->ev_ntab, c->prep_ev.ntab))) return rc;
+      if ((rc = dev_upload(c, c->ev_bpart, c->prep_ev.bpart))) return rc;
       // the big host copies are not needed again (the descriptors are: two-part order)
       std::vector<uint32_t>().swap(c->prep_ev.nlist); std::vector<uint32_t>().swap(c->prep_ev.vloc);
       std::vector<uint32_t>().swap(c->prep_ev.vslot);

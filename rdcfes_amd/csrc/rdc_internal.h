@@ -41,6 +41,7 @@ struct EvDev {
   const uint32_t* vloc = nullptr;
   const uint32_t* vslot = nullptr;
   const HostPrepEv::Node* ntab = nullptr;
+  const uint8_t* bpart = nullptr;
   const uint32_t* wg_perm = nullptr;   // two-part assembly: workgroup order with the interior clusters first (else null)
   int wg_begin = 0, wg_count = -1;
   int nls = 0;

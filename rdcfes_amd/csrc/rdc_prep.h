@@ -123,6 +123,7 @@ struct HostPrepEv {
   std::vector<uint32_t> vloc;        // [n_wg][256] four 8-bit list positions of the visit's vertices, owned first; ~0u = none
   std::vector<uint32_t> vslot;       // [n_wg][256][4]: byte j of word i = column slot of vertex j in the row of vertex i
   std::vector<Node> ntab;            // [n_wg][16]
+  std::vector<uint8_t> bpart;        // [n_wg][256]: mirror block (column node -> row node) of block t = slot * 16 + node when the column node is another node of the cluster, else t itself
   // statistics: element visits and (row, visit) pairs over all workgroups
   int64_t n_visits = 0, n_rows = 0;
   int64_t n_conflicts = 0;           // rows whose node already sits at the same vertex position of their 16-lane group

@@ -187,6 +187,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
   E.vloc.assign((size_t)nwg * BLOCK, 0xFFFFFFFFu);
   E.vslot.assign((size_t)nwg * BLOCK * 4, 0);
   E.ntab.assign((size_t)nwg * MAXN, HostPrepEv::Node{0, 0, 0, 0, 0});
+  E.bpart.assign((size_t)nwg * NBP, 0);
   std::vector<int64_t> rows_w((size_t)nwg, 0), conf_w((size_t)nwg, 0), pass_w((size_t)nwg, 0);
   std::vector<size_t> img_w((size_t)nwg, 0);
 #pragma omp parallel for schedule(dynamic, 256)
@@ -215,6 +216,24 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       if (len > NBP / MAXN) fail = 1;
     }
     d.nb = blk;
+    // mirror blocks: block (x, slot s) whose column node is cluster node x2 != x <-> block (x2, slot of node x in the row of x2)
+    {
+      uint8_t* bp = &E.bpart[(size_t)w * NBP];
+      for (int t2 = 0; t2 < NBP; t2++) bp[t2] = (uint8_t)t2;
+      for (size_t x = 0; x < cl.size(); x++) {
+        const uint32_t n = cl[x];
+        for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) {
+          const uint32_t c2 = (uint32_t)P.bcol[b];
+          if (c2 == n || (int64_t)c2 >= n_owned || cluster_of[c2] != (int32_t)w) continue;
+          const size_t x2 = (size_t)(std::find(cl.begin(), cl.end(), c2) - cl.begin());
+          const int32_t* row2 = &P.bcol[P.bptr[c2]];
+          const int64_t len2 = P.bptr[c2 + 1] - P.bptr[c2];
+          const int64_t s2 = std::find(row2, row2 + len2, (int32_t)n) - row2;
+          if (s2 >= len2) { fail = 1; continue; }   // the node graph is symmetric
+          bp[(size_t)(b - P.bptr[n]) * MAXN + x] = (uint8_t)(s2 * MAXN + (int64_t)x2);
+        }
+      }
+    }
     d.out_doubles = (ob + 1) & ~1u;
     img_w[(size_t)w] = d.out_doubles;
     // visits: vertices permuted owned-first; sorted by the number of owned vertices (descending) so that the waves of

@@ -29,11 +29,16 @@ constexpr int NM = 16;    // moments per node block
 constexpr int NBP = 256;  // node blocks per workgroup (padded): moment m of block b lives at M[m * NBP + b]
 constexpr int MAXN = 16;  // owned nodes per workgroup
 enum { M_E1, M_EoV, M_EPh, M_EQh, M_En, M_Ec, M_Eh, M_Ev, M_Ea, M_Ex, M_Ey, M_ETau, M_EdTc, M_Epv, M_Eg4, M_Edd };
+constexpr bool symmetric_moment(int m) { return m != M_Epv; }   // E_m(i, j) == E_m(j, i)
 
 // One element visit.  X, U: the element's vertices with the `r` cluster-owned ones first (any vertex order is legal:
 // grad phi = cofactor / det and every product used here is invariant under the orientation).
 // Sink: mom(m, i, j, v) adds v to moment m of block (node i, node j), i < r;  rhs(a, i, v) adds to rhs entry a of node i.
-template <int EXP_MODE, class Sink>
+// MIRROR: every moment but M_Epv is symmetric in (i, j), and a column j < i of row i < r is itself an owned row: such a
+// contribution is only added to block (j -> i) by row j, and the expansion adds the moments of the MIRROR block
+// (column node -> row node, HostPrepEv::bpart) to a block's own.  Row position i then issues 15 (4 - i) + 4 + 5 atomics
+// instead of 69 -- the under-filled high row positions of a wave are the cheap ones.
+template <int EXP_MODE, class Sink, bool MIRROR = true>
 RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (&U)[4][5], const int r, Sink& sink) {
   // ---- geometry: unscaled cofactors g_j = det * grad phi_j ------------------------------------------------------
   double e1[3], e2[3], e3[3];
@@ -71,7 +76,7 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
     const double t_[4] = {w18 * beta[1], w18 * beta[2], w18 * beta[3], w18 * beta[4]};                   \
     _Pragma("unroll") for (int i = 0; i < 4; i++) if (i < r) {                                           \
       const double rb_ = Sm_ + t_[i];                                                                    \
-      _Pragma("unroll") for (int j = 0; j < 4; j++) sink.mom(m, i, j, j == i ? rb_ + 3.0 * t_[i] : rb_ + t_[j]); \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) if (!MIRROR || j >= i) sink.mom(m, i, j, j == i ? rb_ + 3.0 * t_[i] : rb_ + t_[j]); \
     }                                                                                                    \
   }
 #define RDC_EV_PT(name, expr) double name[5]; _Pragma("unroll") for (int q = 0; q < 5; q++) name[q] = (expr);
@@ -138,7 +143,7 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
         // pv(i,j) = Tdif_v gk_i F(dT_on)(j) - Tprod_v E(dT Ua v)(i,j)        (coef: B[3][b][2] and -T pv)
         sink.mom(M_Epv, i, j, (j == i ? rb_ + 3.0 * t_[i] : rb_ + t_[j]) + gkT * f_[j]);
         // dd(i,j) * Tdif_v * sum_q JxW_q Tau_on(q)                            (coef: D[3][3])
-        sink.mom(M_Edd, i, j, sTi * (g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2]));
+        if (!MIRROR || j >= i) sink.mom(M_Edd, i, j, sTi * (g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2]));
       }
       sink.rhs(3, i, -(sTi * gki));                                               // RG[3][2]: -dcoef * gk_i
     }

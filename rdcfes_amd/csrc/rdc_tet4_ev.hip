@@ -4,7 +4,7 @@
 // One workgroup = one CLUSTER of <= 16 owned nodes (not necessarily consecutive ids) and the <= 256 elements touching it.
 //   phase 0  zero the moment slice, load the lists, LDS-DMA the node records of the cluster's closure      (as k_tet4_rg5)
 //   phase 1  one thread per element visit: pihna_visit() -> ds_add_f64 of the moments of the rows it owns
-//   phase 2  one thread per node block: 16 moments -> 25 matrix entries (pihna_expand), written to an LDS image of the
+//   phase 2  one thread per node block: 16 moments (+ the symmetric ones of its mirror block) -> 25 matrix entries (pihna_expand), written to an LDS image of the
 //            CSR rows of the cluster's nodes; rhs entries straight to memory
 //   phase 3  the image leaves with 16-byte non-temporal stores, one contiguous CSR segment per node
 // Every CSR value is written exactly once; no global atomics, no colours.  Sums are order-dependent in the last bits.
@@ -39,7 +39,7 @@ struct EvSink {
 template <int EXP_MODE, int MINW, int ABL = 0>
 __global__ void __launch_bounds__(256, MINW)
 k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
-          const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab,
+          const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
           double* __restrict__ rhs, const int nls, const int wg_begin) {
   constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
@@ -64,6 +64,7 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   const uint32_t pl = vloc[(size_t)w * BLOCK + tid];
   const uint4 sl = reinterpret_cast<const uint4*>(vslot)[(size_t)w * BLOCK + tid];
   const HostPrepEv::Desc d = desc[w];
+  const int mirror = (int)bpart[(size_t)w * NBP + tid];   // the block whose symmetric moments are added to this one's (tid: none)
   if (tid < MAXN) snode[tid] = ntab[(size_t)w * MAXN + tid];
   if (wv < rounds) {
     const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
@@ -113,6 +114,11 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   if (has) {
 #pragma unroll
     for (int m = 0; m < NM; m++) e[m] = lds[m * NBP + tid];
+    if (mirror != tid) {   // rdc_tet4_ev.h, MIRROR
+#pragma unroll
+      for (int m = 0; m < NM; m++)
+        if (ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
+    }
   }
   if (tid < (int)d.nown * 5) {   // rhs: R[a][node] -> rhs[node * 5 + a]
     const int n = tid / 5, a = tid - n * 5;
@@ -161,11 +167,11 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t lds_bytes = lds_doubles * sizeof(double);
 #define RDC_EV(MODE, MINW)                                                                                          \
   hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
   if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 3) {   // diagnostic builds (timing only)
 #define RDC_EVA(X)                                                                                                    \
   hipLaunchKernelGGL((k_tet4_ev<3, 3, X>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
     if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else RDC_EVA(3);
 #undef RDC_EVA
     return hipGetLastError();

@@ -376,6 +376,10 @@ int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double*
       if (bn >= d.nown || s2 >= nt[bn].len) continue;
       double e[ev::NM], o[25];
       for (int m = 0; m < ev::NM; m++) e[m] = M[(size_t)m * ev::NBP + t];
+      const uint32_t mir = E.bpart[w * ev::NBP + t];
+      if (mir != t)
+        for (int m = 0; m < ev::NM; m++)
+          if (ev::symmetric_moment(m)) e[m] += M[(size_t)m * ev::NBP + mir];
       ev::pihna_expand(k, e, o);
       const HostPrepEv::Node& nd = nt[bn];
       for (int a = 0; a < 5; a++)
