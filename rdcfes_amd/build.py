@@ -30,6 +30,7 @@ SOURCES = [
     "rdc_model_proteas.hip",
     "rdc_tet4_fast.hip",
     "rdc_tet4_ev.hip",
+    "rdc_tet4_evc.hip",
     "rdc_prep_ev.cpp",
     "rdc_solid.hip",
     "rdc_solid_cl.hip",

@@ -52,6 +52,7 @@ struct rdc_ctx {
   HostPrep prep;
   HostPrepEv prep_ev;          // element-visit lists (PIHNA TET4, shipped pattern); .ok = available
   DevBuf ev_desc, ev_nlist, ev_vloc, ev_vslot, ev_ntab, ev_bpart, ev_perm;
+  bool ev_tried = false;           // the element-visit lists of this mesh have been built (or found impossible)
   int64_t ev_perm_interior = -2;   // "interior_nodes" value the uploaded workgroup order was built for
   int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
@@ -246,6 +247,10 @@ hipError_t launch_specialised<Adpm, rdc_adpm_params>(const LaunchArgs& a, const 
   return launch_rd<Adpm>(a, k);
 }
 
+// k_tet4_evc serves the all-terms Ripf instantiation: not when the reduced one will be chosen (launch_specialised<Ripf>)
+template <class P> bool evc_wanted(const P*, bool) { return false; }
+template <> bool evc_wanted<rdc_ripf_params>(const rdc_ripf_params* p, bool special) { return !(special && RipfReduced::applies(*p)); }
+
 template <class P> bool pihna_pattern_applies(const P*) { return false; }
 template <> bool pihna_pattern_applies<rdc_pihna_params>(const rdc_pihna_params* p) { return PihnaNoCellTransport::applies(*p); }
 
@@ -274,6 +279,27 @@ int part1_workgroups(const rdc_ctx* c) {
     if ((int64_t)c->prep.wg2[(size_t)mid].n0 + c->prep.wg2[(size_t)mid].nnodes <= c->opt_interior) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// element-visit lists (rdc_prep_ev.cpp) of the current mesh: at the upload for five unknowns (PIHNA), on the first
+// assembly for three (RIPF / HCC).  A mesh they cannot describe simply keeps the pair kernels (prep_ev.ok stays false).
+int build_ev_lists(rdc_ctx* c, const uint32_t* conn) {
+  int rc;
+  c->ev_tried = true;
+  const HostPrep& P = c->prep;
+  const std::string ev_err = prep_build_ev(P, conn, (size_t)c->opt_ev_lds, c->prep_ev, c->opt_interior <= P.n_owned ? c->opt_interior : -1);
+  if (!ev_err.empty()) { c->prep_ev = HostPrepEv(); return RDC_OK; }
+  if ((rc = dev_upload(c, c->ev_desc, c->prep_ev.desc))) return rc;
+  if ((rc = dev_upload(c, c->ev_nlist, c->prep_ev.nlist))) return rc;
+  if ((rc = dev_upload(c, c->ev_vloc, c->prep_ev.vloc))) return rc;
+  if ((rc = dev_upload(c, c->ev_vslot, c->prep_ev.vslot))) return rc;
+  if ((rc = dev_upload(c, c->ev_ntab, c->prep_ev.ntab))) return rc;
+  if ((rc = dev_upload(c, c->ev_bpart, c->prep_ev.bpart))) return rc;
+  RDC_HIP(c, hipStreamSynchronize(c->stream));
+  // the big host copies are not needed again (the descriptors are: two-part order)
+  std::vector<uint32_t>().swap(c->prep_ev.nlist); std::vector<uint32_t>().swap(c->prep_ev.vloc);
+  std::vector<uint32_t>().swap(c->prep_ev.vslot);
+  return RDC_OK;
 }
 
 // cluster lists of the producer / consumer HEX8 kernels (three unknowns: solid system and reaction-diffusion models share
@@ -394,6 +420,14 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.rg2.lds_bytes = c->prep.rg2_lds_bytes;
     a.rg2.block = c->prep.rg2_block;
   }
+  // RIPF with all terms on (k_tet4_evc): the element-visit lists are built on the first assembly
+  const bool evc_model = EvcEligible<M>::value && evc_wanted(p, c->opt_special != 0);
+  if (evc_model && a.nen == 4 && !c->ev_tried && c->prep.rg2_ok && c->opt_kernel == 0 && a.strategy == RDC_SCATTER_ROWGATHER && a.variant != RDC_VARIANT_GENERIC) {
+    std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 4);      // the context keeps the connectivity on the device only
+    RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RDC_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = build_ev_lists(c, conn_h.data()))) return rc;
+  }
   // element-visit kernel: default for the shipped-pattern PIHNA / TET4 ("kernel" = 0 or 7); the diagnostic knobs of the
   // pair kernels (ablate, stamps, slim, coefficient form, occupancy 1) and "kernel" = 5 select k_tet4_rg5 instead
   a.use_ev = c->prep_ev.ok && (c->opt_kernel == 0 || c->opt_kernel == 7) && c->opt_moments && !c->opt_slim && (!c->opt_ablate || c->opt_kernel == 7) &&
@@ -411,8 +445,11 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.ev.nls = c->prep_ev.nls;
     a.ev.max_out_doubles = c->prep_ev.max_out_doubles;
   }
-  const bool ev_path = a.use_ev && std::is_same<M, Pihna>::value && a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && c->opt_special &&
-                       a.strategy == RDC_SCATTER_ROWGATHER && pihna_pattern_applies(p);
+  bool pattern_ok = evc_model;
+  if constexpr (std::is_same<M, Pihna>::value) pattern_ok = pihna_pattern_applies(p);
+  const bool ev_path = a.use_ev && (std::is_same<M, Pihna>::value || evc_model) && a.nen == 4 && a.variant != RDC_VARIANT_GENERIC &&
+                       (c->opt_special || !std::is_same<M, Pihna>::value) && a.strategy == RDC_SCATTER_ROWGATHER && pattern_ok;
+  if (!std::is_same<M, Pihna>::value) a.use_ev = ev_path && c->opt_kernel == 0;   // k_tet4_evc (rdc_tet4_fast.hip dispatches on it)
   if (c->opt_part != 0 && ev_path) {
     // two-part assembly on the element-visit lists: the clusters all of whose nodes are interior run in part 1
     if (c->opt_interior < 0) return fail(c, RDC_ERR_STATE, "\"part\" needs \"interior_nodes\"");
@@ -671,23 +708,11 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
   }
   c->prep_ev = HostPrepEv();
   c->ev_perm_interior = -2;
+  c->ev_tried = false;
   if (elem_type == RDC_TET4 && nvar == 5 && P.rg2_ok) {
     // element-visit lists of the PIHNA kernel; a mesh they cannot describe simply keeps the pair kernels
     // "interior_nodes" set BEFORE the upload lets the clusters respect the interior / near-ghost split (two-part assembly)
-    const std::string ev_err = prep_build_ev(P, conn, (size_t)c->opt_ev_lds, c->prep_ev, c->opt_interior <= n_owned ? c->opt_interior : -1);
-    if (ev_err.empty()) {
-      if ((rc = dev_upload(c, c->ev_desc, c->prep_ev.desc))) return rc;
-      if ((rc = dev_upload(c, c->ev_nlist, c->prep_ev.nlist))) return rc;
-      if ((rc = dev_upload(c, c->ev_vloc, c->prep_ev.vloc))) return rc;
-      if ((rc = dev_upload(c, c->ev_vslot, c->prep_ev.vslot))) return rc;
-      if ((rc = dev_upload(c, c->ev_ntab, c->prep_ev.ntab))) return rc;
-      if ((rc = dev_upload(c, c->ev_bpart, c->prep_ev.bpart))) return rc;
-      // the big host copies are not needed again (the descriptors are: two-part order)
-      std::vector<uint32_t>().swap(c->prep_ev.nlist); std::vector<uint32_t>().swap(c->prep_ev.vloc);
-      std::vector<uint32_t>().swap(c->prep_ev.vslot);
-    } else {
-      c->prep_ev = HostPrepEv();
-    }
+    if ((rc = build_ev_lists(c, conn))) return rc;
   }
   const size_t nnz = (size_t)nvar * nvar * P.bptr[n_owned];
   if ((rc = dev_alloc(c, c->val, nnz * sizeof(double)))) return rc;

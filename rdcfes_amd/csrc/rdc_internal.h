@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rdc_kernels.h"
@@ -103,6 +104,14 @@ hipError_t launch_tet4_fast(const LaunchArgs& a, const typename M::K& k);
 hipError_t pack_nodes_pihna(const LaunchArgs& a);
 // element-visit / moment kernel of the shipped-pattern PIHNA TET4 assembly (rdc_tet4_ev.hip)
 hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k);
+// element-visit kernel in coefficient form for the three-unknown TET4 models (rdc_tet4_evc.hip: Ripf, RipfReduced, Hcc, HccMassOnly);
+// the node records must have been packed
+template <class M>
+hipError_t launch_tet4_evc(const LaunchArgs& a, const typename M::K& k);
+// which models run it: measured on K(94) against k_tet4_rg5 (tools/ab.py): Ripf with all terms on 1.41 vs 1.79 ms (the per-element
+// part -- two exp, sqrt, the unit gradient -- dominates); RipfReduced 0.87 vs 0.78, Hcc 0.90 vs 0.65: the pair kernel packs the
+// row atomics of a wave densely, an element visit executes a row position for as few as 10 of 64 lanes
+template <class M> struct EvcEligible { static constexpr bool value = std::is_same<M, Ripf>::value; };
 
 }  // namespace rdc
 #endif

@@ -24,7 +24,8 @@ namespace rdc {
 
 std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_budget_bytes, HostPrepEv& E, int64_t n_interior) {
   E = HostPrepEv();
-  if (P.nen != 4 || P.nvar != 5) return "element-visit lists exist for TET4 with 5 unknowns only";
+  if (P.nen != 4 || (P.nvar != 5 && P.nvar != 3)) return "element-visit lists exist for TET4 with 3 or 5 unknowns only";
+  const size_t nv2 = (size_t)P.nvar * P.nvar;   // CSR values per node block
   const int64_t n_elem = P.n_elem, n_node = P.n_node, n_owned = P.n_owned;
   if (n_owned <= 0) return "no owned nodes";
   if (P.bptr[(size_t)n_owned] >= ((int64_t)1 << 32)) return "more than 2^32 node blocks";
@@ -105,7 +106,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
         n_assigned++;
         assigned_update(n);
         nb += P.bptr[n + 1] - P.bptr[n];
-        img += (size_t)25 * (size_t)(P.bptr[n + 1] - P.bptr[n]) + 1;
+        img += nv2 * (size_t)(P.bptr[n + 1] - P.bptr[n]) + 1;
         for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
           const uint32_t e = inc[k];
           if (emark[e] == stamp) continue;
@@ -140,7 +141,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
         int64_t dv, dt;
         cost_of(c, dv, dt);
         const int64_t lenc = P.bptr[c + 1] - P.bptr[c];
-        if (nvis + dv > BLOCK || ntouch + dt > 255 || nb + lenc > NBP || img + (size_t)25 * (size_t)lenc + 1 > budget_doubles) {
+        if (nvis + dv > BLOCK || ntouch + dt > 255 || nb + lenc > NBP || img + nv2 * (size_t)lenc + 1 > budget_doubles) {
           cluster_of[c] = -2;   // does not fit: out of the race until this cluster is closed
           rejected.push_back(c);
           continue;
@@ -208,10 +209,10 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       HostPrepEv::Node& nd = E.ntab[(size_t)w * MAXN + x];
       const int64_t len = P.bptr[n + 1] - P.bptr[n];
       nd.bptr = (uint32_t)P.bptr[n]; nd.len = (uint16_t)len; nd.blk0 = (uint16_t)x; nd.node = n;   // block (x, slot s) lives at s * MAXN + x
-      const uint32_t phase = (uint32_t)((25 * P.bptr[n]) & 1);
+      const uint32_t phase = (uint32_t)(((int64_t)nv2 * P.bptr[n]) & 1);
       if ((ob & 1) != phase) ob++;          // the image of a segment starts at the 16-byte phase it has in memory
       nd.obase = ob;
-      ob += (uint32_t)(25 * len);
+      ob += (uint32_t)(nv2 * (size_t)len);
       blk += (uint32_t)len;
       if (len > NBP / MAXN) fail = 1;
     }

@@ -929,6 +929,9 @@ static hipError_t launch_fast_impl(const LaunchArgs& a, const typename M::K& k) 
   }
   // the timed region starts after the (tiny) record pack: it brackets the dominant kernel only
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
+  // element visits in coefficient form (rdc_tet4_evc.hip) for the models that profit, when the context has the lists
+  if constexpr (EvcEligible<M>::value)
+  if (a.use_ev && a.ev.n_wg > 0 && a.strategy == RDC_SCATTER_ROWGATHER) return launch_tet4_evc<M>(a, k);
   // models with per-element inputs (M::NELEM > 0) or a local-node aux mask exist only as k_tet4_rg5 and k_tet4_coloured
   if constexpr (M::NELEM == 0 && M::AUX_LOCAL_NODE < 0)
   if (a.strategy == RDC_SCATTER_ROWGATHER && a.rg2.n_wg > 0 && a.rg2.pair_aux && a.rg2.nlist && a.rg2.wg_ntab && a.rg2.block == 256 &&

@@ -11,6 +11,7 @@
 #include "../rdcfes_amd/csrc/rdc_tet4_pihna_moments.h"
 #include "../rdcfes_amd/csrc/rdc_tet4_ev.h"
 #include "../rdcfes_amd/csrc/rdc_hex8_cl.h"
+#include "../rdcfes_amd/csrc/rdc_tet4_evc.h"
 
 using namespace rdc;
 
@@ -180,6 +181,67 @@ int cl_replay(const P* p, const double* xyz, const double* u, const double* aux,
   return 0;
 }
 
+
+// k_tet4_evc replayed on the host from the element-visit lists of the last shim_ev_build and the SAME visit function
+// (tet4_visit): entries accumulated per cluster in the slice layout of the kernel ([entry][slot][node]), then moved to the
+// CSR rows.  val / rhs: the caller pre-fills NaN; entries the lists do not cover stay NaN.
+template <class M>
+struct EvcHostSink {
+  double* S;        // [NE][NBP]
+  double* R;        // [NV][MAXN]
+  int blk[4][4], nloc[4];
+  void ke(int a, int b, int i, int j, double v) { S[(size_t)evc_index<M>(a, b) * ev::NBP + blk[i][j]] += v; }
+  void fe(int a, int i, double v) { R[a * ev::MAXN + nloc[i]] += v; }
+};
+template <class M, class P>
+int evc_replay(const P* p, const double* xyz, const double* u, const double* aux, double* val, double* rhs) {
+  constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1), NE = evc_blocks<M>();
+  if (!g_ev.ok || g_prep.nvar != NV) return 1;
+  const typename M::K k = M::derive(*p);
+  const bool fastexp = exp_mode_of(M::exponent(k)) == M::FAST_EXP_MODE;
+  const HostPrepEv& E = g_ev;
+  std::vector<double> S((size_t)NE * ev::NBP), R((size_t)NV * ev::MAXN);
+  for (size_t w = 0; w < E.desc.size(); w++) {
+    const HostPrepEv::Desc& d = E.desc[w];
+    const HostPrepEv::Node* nt = &E.ntab[w * HostPrepEv::MAXN];
+    std::fill(S.begin(), S.end(), 0.0);
+    std::fill(R.begin(), R.end(), 0.0);
+    for (int x = 0; x < HostPrepEv::BLOCK; x++) {
+      const uint32_t pl = E.vloc[w * HostPrepEv::BLOCK + (size_t)x];
+      if (pl == 0xFFFFFFFFu) continue;
+      double X[4][3], U[4][NV], AX[4][NA];
+      EvcHostSink<M> sink{S.data(), R.data(), {}, {}};
+      int li[4], r = 0;
+      for (int j = 0; j < 4; j++) {
+        li[j] = (int)((pl >> (8 * j)) & 0xFF);
+        const uint32_t n = E.nlist[w * (size_t)E.nls + (size_t)li[j]];
+        for (int c = 0; c < 3; c++) X[j][c] = xyz[3 * (size_t)n + c];
+        for (int v = 0; v < NV; v++) U[j][v] = u[NV * (size_t)n + v];
+        for (int v = 0; v < NA; v++) AX[j][v] = (M::NAUX > 0 && aux) ? aux[(size_t)M::NAUX * n + (M::NAUX > 0 ? v : 0)] : 0.0;
+        r += li[j] < (int)d.nown;
+      }
+      for (int i = 0; i < 4; i++) {
+        sink.nloc[i] = i < r ? li[i] : 0;
+        const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 4 + (size_t)i];
+        for (int j = 0; j < 4; j++) sink.blk[i][j] = i < r ? (int)((word >> (8 * j)) & 0xFF) * ev::MAXN + li[i] : 0;
+      }
+      if (fastexp) tet4_visit<M, M::FAST_EXP_MODE>(k, X, U, AX, r, sink); else tet4_visit<M, 0>(k, X, U, AX, r, sink);
+    }
+    for (uint32_t t = 0; t < (uint32_t)ev::NBP; t++) {
+      const uint32_t bn = t & (ev::MAXN - 1), s2 = t >> 4;
+      if (bn >= d.nown || s2 >= nt[bn].len) continue;
+      const HostPrepEv::Node& nd = nt[bn];
+      for (int a = 0; a < NV; a++)
+        for (int b = 0; b < NV; b++)
+          val[(size_t)NV * NV * nd.bptr + (size_t)a * NV * nd.len + (size_t)NV * s2 + b] =
+              evc_block<M>(a, b) ? S[(size_t)evc_index<M>(a, b) * ev::NBP + t] : 0.0;
+    }
+    for (uint32_t n = 0; n < d.nown; n++)
+      for (int a = 0; a < NV; a++) rhs[(size_t)NV * nt[n].node + a] = R[a * ev::MAXN + n];
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,6 +387,19 @@ int shim_cl_assemble(int model, const void* params, const double* xyz, const dou
             return cl_replay<HccMassOnly>((const rdc_hcc_params*)params, xyz, u, aux, elem, val, rhs);
     case 9: if (!AdpmDecayOnly::applies(*(const rdc_adpm_params*)params)) return 3;
             return cl_replay<AdpmDecayOnly>((const rdc_adpm_params*)params, xyz, u, aux, elem, val, rhs);
+  }
+  return 2;
+}
+
+// model: 1 RIPF, 2 HCC, 7 RIPF reduced, 8 HCC mass only (as shim_row)
+int shim_evc_assemble(int model, const void* params, const double* xyz, const double* u, const double* aux, double* val, double* rhs) {
+  switch (model) {
+    case 1: return evc_replay<Ripf>((const rdc_ripf_params*)params, xyz, u, aux, val, rhs);
+    case 2: return evc_replay<Hcc>((const rdc_hcc_params*)params, xyz, u, aux, val, rhs);
+    case 7: if (!RipfReduced::applies(*(const rdc_ripf_params*)params)) return 3;
+            return evc_replay<RipfReduced>((const rdc_ripf_params*)params, xyz, u, aux, val, rhs);
+    case 8: if (!HccMassOnly::applies(*(const rdc_hcc_params*)params)) return 3;
+            return evc_replay<HccMassOnly>((const rdc_hcc_params*)params, xyz, u, aux, val, rhs);
   }
   return 2;
 }

@@ -420,6 +420,44 @@ def test_two_part_assembly_equals_whole(frac):
     assert rel(valb, val0) < 1e-13 and rel(rhsb, rhs0) < 1e-13
 
 
+def test_two_part_assembly_ripf_element_visits(oracle):
+    """the all-terms RIPF instantiation runs on element visits (k_tet4_evc): two-part assembly on its cluster lists, and the
+    pair kernel ("kernel" = 5) as the cross-check"""
+    conn, xyz = synth.kuhn_tet_mesh(10, order="lex")
+    u, aux = synth.ripf_fields(xyz)
+    p = ripf_params_from_dict(synth.ripf_param_dict("full"))
+    _, _, val0, rhs0 = oracle.assemble(1, 4, conn, xyz, 3, p, u_old=u, aux=aux)
+    n_int = int(0.4 * xyz.shape[0])
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("interior_nodes", n_int)
+        ctx.mesh_upload(4, conn, xyz, 3)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.field_upload(FIELD_AUX_NODAL, aux)
+        ctx.assemble_ripf(p)
+        val, rhs = ctx.csr_download()
+        assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
+        rp, _ = ctx.csr_pattern()
+        ctx.field_upload(FIELD_OLD_SOLUTION, 0.5 * u)
+        ctx.assemble_ripf(p)
+        val1, rhs1 = ctx.csr_download()
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.set_option("part", 1)
+        ctx.assemble_ripf(p)
+        vala, rhsa = ctx.csr_download()
+        ctx.set_option("part", 2)
+        ctx.assemble_ripf(p)
+        valb, rhsb = ctx.csr_download()
+        ctx.set_option("part", 0)
+        ctx.set_option("kernel", 5)
+        ctx.assemble_ripf(p)
+        valc, rhsc = ctx.csr_download()
+    row_of = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+    new_rows = np.union1d(np.flatnonzero(rhsa != rhs1), np.unique(row_of[vala != val1]))
+    assert new_rows.size > 0.5 * 3 * n_int and new_rows.max() < 3 * n_int     # part 1: most interior rows, nothing else
+    assert rel(valb, val0) < TOL and rel(rhsb, rhs0) < TOL
+    assert rel(valc, val0) < TOL and rel(rhsc, rhs0) < TOL
+
+
 def test_two_part_assembly_fallback_paths():
     """Paths that cannot launch sub-ranges (HEX8 generic kernels, the coloured strategy) write nothing in part 1 and
     everything in part 2 -- the contract rdc_assembly.h states for rdc_set_option("part")."""

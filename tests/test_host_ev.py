@@ -87,3 +87,54 @@ def test_ev_replay_clamped_branches(oracle, shim):
     assert np.array_equal(np.isnan(val), np.isnan(val0)) and np.array_equal(np.isnan(rhs), np.isnan(rhs0))
     ok, okr = ~np.isnan(val0), ~np.isnan(rhs0)
     assert rel(val[ok], val0[ok]) < 1e-10 and rel(rhs[okr], rhs0[okr]) < 1e-10
+
+
+# ---- coefficient-form element visits (rdc_tet4_evc.h) for the three-unknown models ------------------------------------------
+def _evc(shim, model, p, conn, xyz, u, aux, n_owned, budget=54000):
+    conn = np.ascontiguousarray(conn, dtype=np.uint32)
+    rc = shim.shim_prep_build(4, C.c_int64(conn.shape[0]), C.c_int64(xyz.shape[0]), C.c_int64(n_owned),
+                              conn.ctypes.data_as(C.POINTER(C.c_uint32)), 3, C.c_int64(60 * 1024), 256)
+    assert rc == 0, shim.shim_prep_error()
+    stats = (C.c_int64 * 6)()
+    rc = shim.shim_ev_build(C.c_int64(budget), stats)
+    assert rc == 0, shim.shim_prep_error()
+    assert stats[5] == n_owned
+    bptr = np.empty(shim.shim_prep_size(0), dtype=np.int64)
+    shim.shim_prep_copy(0, bptr.ctypes.data_as(C.c_void_p))
+    val = np.full(9 * bptr[n_owned], np.nan)
+    rhs = np.full(3 * n_owned, np.nan)
+    keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (xyz, u, aux)]
+    ptr = [a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None for a in keep]
+    rc = shim.shim_evc_assemble(model, C.byref(p), ptr[0], ptr[1], ptr[2], val.ctypes.data_as(C.POINTER(C.c_double)),
+                                rhs.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0, rc
+    return val, rhs
+
+
+@pytest.mark.parametrize("order", ["lex", "random"])
+@pytest.mark.parametrize("params", ["full", "shipped"])
+def test_evc_replay_ripf(oracle, shim, order, params):
+    from rdcfes_amd import ripf_params_from_dict
+    conn, xyz = synth.kuhn_tet_mesh(6, order=order)
+    u, aux = synth.ripf_fields(xyz)
+    p = ripf_params_from_dict(synth.ripf_param_dict(params))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_RIPF, 4, conn, xyz, 3, p, u_old=u, aux=aux)
+    val, rhs = _evc(shim, 1, p, conn, xyz, u, aux, xyz.shape[0])
+    assert np.isfinite(val).all() and np.isfinite(rhs).all()
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
+    if params == "shipped":   # the reduced instantiation of the shipped parameter pattern gives the same numbers
+        val2, rhs2 = _evc(shim, 7, p, conn, xyz, u, aux, xyz.shape[0])
+        assert rel(val2, val0) < 1e-10 and rel(rhs2, rhs0) < 1e-10
+
+
+@pytest.mark.parametrize("params", ["full", "shipped"])
+def test_evc_replay_hcc_on_a_ghosted_partition(oracle, shim, params):
+    from rdcfes_amd import hcc_params_from_dict
+    conn, xyz = synth.kuhn_tet_mesh(6, order="random")
+    n_owned = int(0.6 * xyz.shape[0])
+    conn = conn[(conn < n_owned).any(axis=1)]
+    u = synth.hcc_fields(xyz)
+    p = hcc_params_from_dict(synth.hcc_param_dict(params))
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_HCC, 4, conn, xyz, 3, p, u_old=u, n_owned=n_owned)
+    val, rhs = _evc(shim, 2 if params == "full" else 8, p, conn, xyz, u, None, n_owned)
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
