@@ -65,10 +65,9 @@ def _replay(shim, model, p, conn, xyz, u, aux, tracts, n_owned, lim=(24, 192, 64
     shim.shim_prep_copy(0, bptr.ctypes.data_as(C.c_void_p))
     val = np.full(9 * bptr[n_owned], np.nan)
     rhs = np.full(3 * n_owned, np.nan)
-    dp = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
     keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (xyz, u, aux, tracts)]
     ptr = [a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None for a in keep]
-    rc = shim.shim_cl_assemble(model, C.byref(p), ptr[0], ptr[1], ptr[2], ptr[3], dp(val) if False else val.ctypes.data_as(C.POINTER(C.c_double)),
+    rc = shim.shim_cl_assemble(model, C.byref(p), ptr[0], ptr[1], ptr[2], ptr[3], val.ctypes.data_as(C.POINTER(C.c_double)),
                                rhs.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == 0, rc
     return val, rhs
