@@ -420,6 +420,43 @@ def test_two_part_assembly_equals_whole(frac):
     assert rel(valb, val0) < 1e-13 and rel(rhsb, rhs0) < 1e-13
 
 
+@pytest.mark.parametrize("nen", [4, 8])
+@pytest.mark.parametrize("model", ["pihna", "ripf", "hcc", "adpm"])
+def test_shipped_pattern_instantiations_agree_with_the_general_ones(model, nen):
+    """the parameter-pattern instantiations (selected from the VALUES of the four shipped input files) drop products that
+    upstream multiplies by zero: with "specialise" = 0 the general instantiation runs on the same parameters and the
+    results agree to rounding (advisor finding, round 1)"""
+    from rdcfes_amd import FIELD_ELEM_TRACTS, adpm_params_from_dict
+    conn, xyz = synth.kuhn_tet_mesh(6, order="random") if nen == 4 else synth.hex_mesh(6, jitter=0.15, order="random")
+    aux = tracts = None
+    if model == "pihna":
+        nv, p, u, call = 5, pihna_params_from_dict(synth.pihna_param_dict("shipped")), synth.pihna_fields(xyz), "assemble_pihna"
+    elif model == "ripf":
+        nv, p, call = 3, ripf_params_from_dict(synth.ripf_param_dict("shipped")), "assemble_ripf"
+        u, aux = synth.ripf_fields(xyz)
+    elif model == "hcc":
+        nv, p, u, call = 3, hcc_params_from_dict(synth.hcc_param_dict("shipped")), synth.hcc_fields(xyz), "assemble_hcc"
+    else:
+        nv, p, call = 3, adpm_params_from_dict(synth.adpm_param_dict("shipped"), time=3.0), "assemble_adpm"
+        u, tracts = synth.adpm_fields(xyz, conn.shape[0])
+    out = []
+    for special in (1, 0):
+        with AssemblyContext(0) as ctx:
+            ctx.set_option("specialise", special)
+            ctx.mesh_upload(nen, conn, xyz, nv)
+            ctx.field_upload(FIELD_OLD_SOLUTION, u)
+            if aux is not None:
+                ctx.field_upload(FIELD_AUX_NODAL, aux)
+            if tracts is not None:
+                ctx.field_upload(FIELD_ELEM_TRACTS, tracts)
+            getattr(ctx, call)(p)
+            out.append(ctx.csr_download())
+    (val1, rhs1), (val0, rhs0) = out
+    assert rel(val1, val0) < 1e-13 and rel(rhs1, rhs0) < 1e-13
+    # entry by entry: absolute differences at the rounding level of the largest entry of the row block
+    assert np.abs(val1 - val0).max() <= 1e-12 * np.abs(val0).max()
+
+
 def test_two_part_assembly_ripf_element_visits(oracle):
     """the all-terms RIPF instantiation runs on element visits (k_tet4_evc): two-part assembly on its cluster lists, and the
     pair kernel ("kernel" = 5) as the cross-check"""
