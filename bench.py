@@ -153,6 +153,9 @@ def extra_configs():
     ph = hcc_params_from_dict(synth.hcc_param_dict("full"))
     out.append(time_config("cfg5 (RD half): HCC HEX8 H(126) on the deformed mesh, all rates non-zero", 8, conn, x, 3,
                            lambda c: c.field_upload(FIELD_OLD_SOLUTION, uh), lambda c: c.assemble_hcc(ph), 3, reps=6))
+    ps = hcc_params_from_dict(synth.hcc_param_dict("shipped"))
+    out.append(time_config("cfg5 (RD half, shipped): HCC HEX8 H(126) on the deformed mesh, params run/Coupled/HCC/input.dat (every rate zero)", 8, conn, x, 3,
+                           lambda c: c.field_upload(FIELD_OLD_SOLUTION, uh), lambda c: c.assemble_hcc(ps), 3, reps=6))
     em = (np.linalg.norm(Xu[conn].mean(axis=1) - 0.5, axis=1) < 0.3).astype(np.int32)
     mats = [SolidMaterial(2.0e3, 0.4, 0.0, (0.0, 0.0, 0.0)), SolidMaterial(2.0e3, 0.4, 0.0, (0.3, 0.3, 0.3))]
     se0, ss0 = synth.boundary_sides(8, conn, Xu, 2, 0.0)
