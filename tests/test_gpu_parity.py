@@ -233,6 +233,29 @@ def test_solid_parity(oracle, nen, n, use_symmetry, jac, solid_kernel, solid_gat
         assert rel(rhs2, rhs0) < TOL
 
 
+@pytest.mark.parametrize("solid_kernel", [0, 2])
+def test_solid_parity_on_a_ghosted_partition(oracle, solid_kernel):
+    """SolidSystem rows of the owned nodes only (one rank of a partition): the cluster lists of the fused kernel hold owned
+    nodes, its producers read ghost nodes' coordinates"""
+    conn, Xu, x, em, mats, fibre, _ = _solid_case(8, 6)
+    n_owned = int(0.55 * Xu.shape[0])
+    keep = (conn < n_owned).any(axis=1)
+    conn, em, fibre = conn[keep], em[keep], fibre[keep]
+    sp = SolidParams(0.4, 1.0e5, 0, 0)
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_SOLID, 8, conn, x, 3, sp, xyz_undeformed=Xu, elem_fibre=fibre,
+                                       elem_material=em, materials=mats, request_jacobian=True, n_owned=n_owned)
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("solid_kernel", solid_kernel)
+        ctx.mesh_upload(8, conn, x, 3, n_owned=n_owned)
+        ctx.field_upload(FIELD_UNDEFORMED_XYZ, Xu)
+        ctx.field_upload(FIELD_ELEM_FIBRE, fibre)
+        ctx.solid_set_materials(em, mats)
+        ctx.solid_assemble(sp, True)
+        val, rhs = ctx.csr_download()
+    assert rhs.size == 3 * n_owned
+    assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
 def test_clamp_nonnegative(oracle):
     conn, xyz = synth.kuhn_tet_mesh(3)
     u = np.random.default_rng(3).standard_normal((xyz.shape[0], 5))
