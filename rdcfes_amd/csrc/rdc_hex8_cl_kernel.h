@@ -14,7 +14,7 @@ constexpr bool hex8_cl_block(int a, int b) {
   return nz;
 }
 
-template <class M, int EXP_MODE, int CW, int PW>
+template <class M, int EXP_MODE, int CW, int PW, int PPR>
 __global__ void __launch_bounds__((CW + PW) * 64, 2)
 k_hex8_cl(const MeshDev m, const typename M::K k, const HostPrepCl::Desc* __restrict__ desc, const HostPrepCl::Node* __restrict__ ntab,
           const uint32_t* __restrict__ eid, const uint32_t* __restrict__ pair, const uint32_t* __restrict__ pslot,
@@ -71,11 +71,19 @@ k_hex8_cl(const MeshDev m, const typename M::K k, const HostPrepCl::Desc* __rest
       }
     }
     const double* ED = M::NELEM > 0 ? elem + (int64_t)e * M::NELEM : nullptr;
-    if (plive) hex8_cl_produce<M>(k, X, U, AX, ED, 0, lds + pl * R::STRIDE);
+    // PPR points per round and barrier: buffer (round & 1) holds the records [point in round][element]
+    if (plive) {
+#pragma unroll
+      for (int x = 0; x < PPR; x++) hex8_cl_produce<M>(k, X, U, AX, ED, x, lds + (x * MAXE + pl) * R::STRIDE);
+    }
     __syncthreads();
 #pragma unroll 1
-    for (int q = 0; q < 8; q++) {   // one point ahead of the consumers
-      if (plive && q + 1 < 8) hex8_cl_produce<M>(k, X, U, AX, ED, q + 1, lds + (((q + 1) & 1) * MAXE + pl) * R::STRIDE);
+    for (int q = 0; q < 8; q += PPR) {   // one round ahead of the consumers
+      if (plive && q + PPR < 8) {
+#pragma unroll
+        for (int x = 0; x < PPR; x++)
+          hex8_cl_produce<M>(k, X, U, AX, ED, q + PPR + x, lds + (((((q / PPR) + 1) & 1) * PPR + x) * MAXE + pl) * R::STRIDE);
+      }
       __syncthreads();
     }
     zero_image();
@@ -91,10 +99,14 @@ k_hex8_cl(const MeshDev m, const typename M::K k, const HostPrepCl::Desc* __rest
   const uint32_t pr = pair[(size_t)w * MAXP + tid];
   const bool cvalid = pr != 0xFFFFFFFFu;
   if (cvalid) { le = (int)(pr & 0xFF); li = (int)((pr >> 8) & 0xFF); na = (int)((pr >> 16) & 0xFF); }
-  __syncthreads();                  // producers: point 0
+  __syncthreads();                  // producers: the first round of points
 #pragma unroll 1
-  for (int q = 0; q < 8; q++) {
-    if (cvalid) hex8_cl_consume<M, EXP_MODE>(k, lds + ((q & 1) * MAXE + le) * R::STRIDE, q, li, acc, fe);
+  for (int q = 0; q < 8; q += PPR) {
+    if (cvalid) {
+#pragma unroll
+      for (int x = 0; x < PPR; x++)
+        hex8_cl_consume<M, EXP_MODE>(k, lds + ((((q / PPR) & 1) * PPR + x) * MAXE + le) * R::STRIDE, q + x, li, acc, fe);
+    }
     __syncthreads();
   }
   zero_image();
@@ -314,8 +326,8 @@ inline size_t hex8_clp_lds_bytes(int cw, int pw, size_t max_row_doubles) {
 }
 
 template <class M>
-inline size_t hex8_cl_lds_bytes(int cw, int pw, size_t max_row_doubles) {
-  const size_t points = (size_t)2 * pw * 64 * Hex8Rec<M>::STRIDE;
+inline size_t hex8_cl_lds_bytes(int cw, int pw, size_t max_row_doubles, int ppr) {
+  const size_t points = (size_t)2 * ppr * pw * 64 * Hex8Rec<M>::STRIDE;
   const size_t image = ((max_row_doubles + 1) & ~(size_t)1) + (size_t)M::NV * cw * 8;
   return sizeof(double) * (points > image ? points : image);
 }
@@ -333,11 +345,18 @@ static hipError_t launch_hex8_cl(const LaunchArgs& a, const typename M::K& k) {
                        a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs, a.cl.n_wg, (int)((a.cl.max_row_doubles + 1) & ~(size_t)1), a.opt_ablate);
     return hipGetLastError();
   }
-  const size_t bytes = hex8_cl_lds_bytes<M>(CW, PW, a.cl.max_row_doubles);
-  static bool attr = false;  // per instantiation
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_hex8_cl<M, EXP_MODE, CW, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
-  hipLaunchKernelGGL((k_hex8_cl<M, EXP_MODE, CW, PW>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab,
-                     a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs);
+  // quadrature points per round and workgroup barrier: the model's choice (M::HEX_CL_POINTS); "prefetch" = 1 forces one
+#define RDC_HEX8_CL(PPR)                                                                                                              \
+  {                                                                                                                                   \
+    const size_t bytes = hex8_cl_lds_bytes<M>(CW, PW, a.cl.max_row_doubles, PPR);                                                     \
+    static bool attr = false; /* per instantiation */                                                                                  \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_hex8_cl<M, EXP_MODE, CW, PW, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+    hipLaunchKernelGGL((k_hex8_cl<M, EXP_MODE, CW, PW, PPR>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab, \
+                       a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs);                                           \
+  }
+  if constexpr (M::HEX_CL_POINTS == 2) { if (a.opt_pf == 1) RDC_HEX8_CL(1) else RDC_HEX8_CL(2) }
+  else RDC_HEX8_CL(1)
+#undef RDC_HEX8_CL
   return hipGetLastError();
 }
 

@@ -113,6 +113,7 @@ struct PihnaK {  // src/pihna.C:358-381
 };
 
 struct Pihna {
+  static constexpr int HEX_CL_POINTS = 1;   // k_hex8_cl: quadrature points per workgroup barrier
   static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr bool HEX_REF_GRADS = true;  // HEX8 generic evaluator: inverse Jacobian applied to reference gradients (rdc_row.h)
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
@@ -327,6 +328,7 @@ struct RipfK {
 };
 
 struct Ripf {
+  static constexpr int HEX_CL_POINTS = 1;   // k_hex8_cl: quadrature points per workgroup barrier
   static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr bool HEX_REF_GRADS = false; // three gradient fields: forming grad phi of all nodes measured faster (H(80) 2.08 vs 2.36 ms)
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
@@ -549,6 +551,7 @@ struct HccK {
 };
 
 struct Hcc {
+  static constexpr int HEX_CL_POINTS = 2;   // k_hex8_cl: quadrature points per workgroup barrier (two: 2.7 vs 3.0 ms on H(126); the heavier models spill)
   static constexpr bool HEX_STAGED = true;   // node-staged HEX8 row gather: 1.32 -> 1.07 ms on H(80) (tools/hex_ab.py)
   static constexpr bool HEX_REF_GRADS = true;
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
@@ -624,6 +627,7 @@ struct Hcc {
 // the doubled [1][1] = 2 (App. D.1-2) -- and rhs = old solution; the blocks [2][0], [2][1] are -T*0*n = -0.  No
 // gradient, no pow.  Exact for finite states; the host selects it from the parameter values.
 struct HccMassOnly : Hcc {
+  static constexpr int HEX_CL_POINTS = 1;   // stays at 148 registers = three workgroups per CU
   static inline bool applies(const rdc_hcc_params& p) {
     return p.produce_l == 0.0 && p.produce_c == 0.0 && p.diffuse_c == 0.0 && p.necrosis_l == 0.0 && p.necrosis_c == 0.0;
   }
@@ -697,6 +701,7 @@ struct AdpmK {
 };
 
 struct Adpm {
+  static constexpr int HEX_CL_POINTS = 1;   // k_hex8_cl: quadrature points per workgroup barrier
   static constexpr bool HEX_STAGED = true;   // node-staged HEX8 row gather: 2.85 -> 2.12 ms on H(80) (tools/hex_ab.py)
   static constexpr bool HEX_REF_GRADS = true;
   static constexpr int AUX_LOCAL_NODE = -1;  // aux nodal values of every element node are read
@@ -854,6 +859,7 @@ struct ProteasK {
 };
 
 struct Proteas {
+  static constexpr int HEX_CL_POINTS = 1;   // k_hex8_cl: quadrature points per workgroup barrier
   static constexpr bool HEX_STAGED = false;  // node-staged HEX8 row gather measured slower for this model (tools/hex_ab.py)
   static constexpr bool HEX_REF_GRADS = true;
   static constexpr int AUX_LOCAL_NODE = 1;

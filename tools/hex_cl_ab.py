@@ -19,8 +19,8 @@ with AssemblyContext(0) as c:
     for rnd in range(2):
         for name, hk, ab in (("persistent", 2, 0), ("one workgroup per cluster (default)", 0, 0), ("pair kernel (staged)", 1, 0), ("consumers idle", 2, 1), ("producers idle", 2, 2),
                              ("no compute", 2, 3), ("no atomics", 2, 8), ("no copy-out", 2, 16), ("no compute, no atomics", 2, 11), ("no compute, no copy-out", 2, 19),
-                             ("barriers and loads only", 2, 27), ("compute only", 2, 24), ("element-major pair order, persistent", 2, 0), ("element-major, one workgroup per cluster", 0, 0)):
-            c.set_option("hex_kernel", hk); c.set_option("ablate", ab); c.set_option("solid_cl_order", 1 if name.startswith("element-major") else 0)
+                             ("barriers and loads only", 2, 27), ("compute only", 2, 24), ("element-major pair order, persistent", 2, 0), ("element-major, one workgroup per cluster", 0, 0), ("one point per round", 0, 0)):
+            c.set_option("hex_kernel", hk); c.set_option("ablate", ab); c.set_option("prefetch", 1 if name.startswith("one point") else 0); c.set_option("solid_cl_order", 1 if name.startswith("element-major") else 0)
             c.assemble_hcc(p); c.synchronize()
             c.timing_enable(True)
             for _ in range(3): c.assemble_hcc(p)
