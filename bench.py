@@ -90,14 +90,16 @@ def time_config(name, nen, conn, xyz, nvar, setup, call, n_in, solid=False, reps
         ctx.timing_enable(True)
         for _ in range(reps):
             call(ctx)
-        ms, n = ctx.timing_sum_ms()
+        samples = ctx.timing_samples_ms()
         ctx.timing_enable(False)
-        ms /= max(n, 1)
+        n = len(samples)
+        ms = float(sum(samples)) / max(n, 1)
         _, nnz = ctx.csr_dims()
     b = algorithmic_bytes(nen, conn.shape[0], xyz.shape[0], xyz.shape[0], nvar, n_in, nnz, solid)
     out = {"workload": name, "elements": int(conn.shape[0]), "nodes": int(xyz.shape[0]), "nnz": int(nnz),
            "kernel_ms": ms, "elements_per_s": conn.shape[0] / (ms * 1e-3), "algorithmic_bytes_per_launch": int(b),
            "achieved_GBps": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches_timed": int(n),
+           "kernel_ms_median": float(np.median(samples)) if samples else None, "kernel_ms_min": float(min(samples)) if samples else None,
            "host_prep_s": round(prep_s, 2)}
     if note:
         out["note"] = note
@@ -355,7 +357,8 @@ def main():
     t_host = time.perf_counter() - t0       # host time to ENQUEUE the steps (no device wait inside step())
     fence()
     dt = time.perf_counter() - t0
-    kern_ms, n_calls = ctx.timing_sum_ms()
+    samples = ctx.timing_samples_ms()     # HIP events around the assembly kernel of every call, on the context's stream
+    kern_ms, n_calls = float(sum(samples)), len(samples)
     ctx.timing_enable(False)
     multi = None
     if world > 1:
@@ -403,6 +406,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": kern_avg_ms,
+                         "kernel_ms_median": float(np.median(samples)) if samples and world == 1 else None,
+                         "kernel_ms_min": float(min(samples)) if samples and world == 1 else None, "launches_timed": len(samples),
                          "fp64_tflops": fp64_tflops, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
                          "fp64_frac": fp64_tflops / FP64_PEAK_TFLOPS if fp64_tflops else None,
                          "profile_kernel": prof_kernel,

@@ -353,6 +353,8 @@ int rdc_timing_last_ms(rdc_ctx* ctx, float* ms);
 /* sum of the device times of every assemble call since the last enable / sum, and their count;
  * synchronises on the recorded events and resets the pool (no host sync happens inside assemble) */
 int rdc_timing_sum_ms(rdc_ctx* ctx, float* total_ms, int* n_calls);
+/* the same, call by call (oldest first) into ms[0 .. min(*n_calls, capacity)): for the median / minimum of a timed run */
+int rdc_timing_samples_ms(rdc_ctx* ctx, float* ms, int capacity, int* n_calls);
 
 /* diagnostic only: call with host_out == NULL to arm (the next shipped-parameter PIHNA/TET4 assembly then
  * runs a separately compiled kernel that records s_memtime stamps per workgroup phase; *n_written = number

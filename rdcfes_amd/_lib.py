@@ -60,6 +60,7 @@ SIGNATURES = {
     "rdc_timing_enable": (C.c_int, [ctx_p, C.c_int]),
     "rdc_timing_last_ms": (C.c_int, [ctx_p, P(C.c_float)]),
     "rdc_timing_sum_ms": (C.c_int, [ctx_p, P(C.c_float), P(C.c_int)]),
+    "rdc_timing_samples_ms": (C.c_int, [ctx_p, P(C.c_float), C.c_int, P(C.c_int)]),
     "rdc_debug_stamps": (C.c_int, [ctx_p, P(C.c_longlong), i64, P(i64)]),
 }
 

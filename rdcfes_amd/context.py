@@ -256,3 +256,10 @@ class AssemblyContext:
         ms, n = C.c_float(), C.c_int()
         self._ck(self._lib.rdc_timing_sum_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_samples_ms(self, capacity=4096):
+        """device ms of every assemble call since the last enable / sum / samples (oldest first); resets the pool."""
+        buf = (C.c_float * capacity)()
+        n = C.c_int()
+        self._ck(self._lib.rdc_timing_samples_ms(self._h, buf, capacity, C.byref(n)))
+        return [buf[i] for i in range(min(n.value, capacity))]

@@ -1310,4 +1310,20 @@ int rdc_timing_sum_ms(rdc_ctx* c, float* total_ms, int* n_calls) {
   return RDC_OK;
 }
 
+int rdc_timing_samples_ms(rdc_ctx* c, float* out, int capacity, int* n_calls) {
+  if (!c || !out || !n_calls || capacity < 0) return RDC_ERR_INVALID;
+  int rc = set_device(c);
+  if (rc) return rc;
+  int n = 0;
+  for (size_t x = 0; x + 1 < c->ev_used; x += 2, n++) {
+    float ms = 0.0f;
+    RDC_HIP(c, hipEventSynchronize(c->ev[x + 1]));
+    RDC_HIP(c, hipEventElapsedTime(&ms, c->ev[x], c->ev[x + 1]));
+    if (n < capacity) out[n] = ms;
+  }
+  *n_calls = n;
+  c->ev_used = 0;
+  return RDC_OK;
+}
+
 }  // extern "C"

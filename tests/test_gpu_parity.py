@@ -303,6 +303,13 @@ def test_timing_hook():
         ctx.assemble_pihna(p)
         ctx.synchronize()
         assert 0.0 < ctx.timing_last_ms() < 1e4
+        for _ in range(4):
+            ctx.assemble_pihna(p)
+        samples = ctx.timing_samples_ms()          # one device time per call, oldest first; resets the pool
+        assert len(samples) == 5 and all(0.0 < t < 1e4 for t in samples)
+        ctx.assemble_pihna(p)
+        total, n = ctx.timing_sum_ms()
+        assert n == 1 and 0.0 < total < 1e4
 
 
 # ---- two ranks (gloo, host-staged halo) sharing the one GPU of the test box ---------------------
