@@ -19,9 +19,15 @@ with AssemblyContext(0) as c:
     sel = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
     for rnd in range(2):
       for idx, (name, opts) in enumerate((("fused 3+1 waves (default)", {}), ("fused 6+2 waves", {"solid_cl_waves": 62}), ("two-pass", {"solid_kernel": 2}),
-                         ("two-pass, pass 1 without stores", {"solid_kernel": 2, "solid_store": 2}), ("fused 3+1, node-distinct pair order", {"solid_cl_order": 0}))):
+                         ("two-pass, pass 1 without stores", {"solid_kernel": 2, "solid_store": 2}), ("fused 3+1, node-distinct pair order", {"solid_cl_order": 0}),
+                         # timing diagnostics of k_solid_cl (results wrong by construction): "solid_store" bit mask
+                         # 1 = consumers idle, 2 = producers idle, 4 = image not zeroed, 8 = no atomics, 16 = no copy-out, 32 = no element loads
+                         ("fused, consumers idle", {"solid_store": 1}), ("fused, producers idle", {"solid_store": 2}), ("fused, no compute", {"solid_store": 3}),
+                         ("fused, no compute, no atomics", {"solid_store": 11}), ("fused, no compute, no copy-out", {"solid_store": 19}),
+                         ("fused, no compute, no element loads", {"solid_store": 35}), ("fused, barriers + lists only", {"solid_store": 63}),
+                         ("fused, compute only", {"solid_store": 28}))):
         if sel is not None and idx not in sel: continue
-        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31); c.set_option("solid_cl_order", 1); c.set_option("solid_cl_order", 1)
+        c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31); c.set_option("solid_cl_order", 1)
         for k, v in opts.items(): c.set_option(k, v)
         c.solid_assemble(sp, True); c.synchronize()
         c.timing_enable(True)
