@@ -314,6 +314,10 @@ int ensure_cluster_lists(rdc_ctx* c, int order_of_caller) {
   lim.max_nodes = cw * 8; lim.max_pairs = cw * 64; lim.max_elems = pw * 64;
   // the LDS image of the cluster's CSR rows overlays the point buffers of the solid kernel (2 x 64 pw records of 49 doubles)
   lim.max_row_doubles = (int)(2 * pw * 64 * 49) - 3 * cw * 8 - 2;
+  if (c->prep.nvar == 5) {   // k_hex8_cl_rows: the image holds one equation row of the cluster's nodes and overlays its smaller point buffers
+    lim.img_per_block = 5;
+    lim.max_row_doubles = 5 * 27 * lim.max_nodes + 5 * lim.max_nodes;
+  }
   lim.pair_order = want_order;
   HostPrepCl cl;
   std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
@@ -494,7 +498,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     c->part1_packed = false;
   }
   // HEX8, three unknowns: producer / consumer cluster kernel (whole-mesh assembly only; a two-part call uses the pair kernels)
-  if (a.nen == 8 && M::NV == 3 && c->opt_hex_kernel != 1 && c->opt_part == 0 && a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
+  if (a.nen == 8 && (M::NV == 3 || M::NV == 5) && c->opt_hex_kernel != 1 && c->opt_part == 0 && a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
     if ((rc = ensure_cluster_lists(c, 0))) return rc;
     if (c->solid_cl_state == 1) {
       a.cl = cluster_view(c);

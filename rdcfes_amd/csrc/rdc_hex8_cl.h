@@ -93,13 +93,11 @@ RDC_HD void hex8_cl_produce(const typename M::K& k, const double (&X)[8][3], con
   for (int v = 0; v < R::NA; v++) rec[R::AQ + v] = aq[v];
 }
 
-// contribution of the point whose record is `rec` to the row of local node irow
+// what the point whose record is `rec` contributes to the row of local node irow, before the accumulation
 template <class M, int EXP_MODE>
-RDC_HD void hex8_cl_consume(const typename M::K& k, const double* rec, int q, int irow, double (&acc)[M::NV][M::NV][8],
-                            double (&fe)[M::NV]) {
+RDC_HD void hex8_cl_point(const typename M::K& k, const double* rec, int q, int irow, RowPoint<M, 8>& P) {
   constexpr int NG = M::NG;
   using R = Hex8Rec<M>;
-  RowPoint<M, 8> P;
   P.W = rec[6];
 #pragma unroll
   for (int n = 0; n < 8; n++) P.N[n] = kHex8Tab.N[q][n];
@@ -127,7 +125,23 @@ RDC_HD void hex8_cl_consume(const typename M::K& k, const double* rec, int q, in
   typename M::Pt pt;
   M::template point<EXP_MODE>(k, uq, aq, pt);
   M::coef(k, pt, P.c);
+}
+
+// contribution of that point to the row of local node irow: all equation rows (three unknowns) ...
+template <class M, int EXP_MODE>
+RDC_HD void hex8_cl_consume(const typename M::K& k, const double* rec, int q, int irow, double (&acc)[M::NV][M::NV][8],
+                            double (&fe)[M::NV]) {
+  RowPoint<M, 8> P;
+  hex8_cl_point<M, EXP_MODE>(k, rec, q, irow, P);
   rd_point_accum<M, 8>(P, acc, fe);
+}
+// ... or equation row A only (five unknowns: the NV x NV x 8 accumulator does not fit the register file; everything of
+// coef() that row A does not read is dead code)
+template <class M, int EXP_MODE, int A>
+RDC_HD void hex8_cl_consume_row(const typename M::K& k, const double* rec, int q, int irow, double (&acc)[M::NV][8], double& fe) {
+  RowPoint<M, 8> P;
+  hex8_cl_point<M, EXP_MODE>(k, rec, q, irow, P);
+  rd_point_accum_row<M, 8, A>(P, acc, fe);
 }
 
 }  // namespace rdc

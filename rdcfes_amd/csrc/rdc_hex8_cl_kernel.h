@@ -4,6 +4,8 @@
 #include "rdc_hex8_cl.h"
 #include "rdc_internal.h"
 
+#include <type_traits>
+
 namespace rdc {
 
 // block (a, b) of the model is structurally non-zero (any of the A / B / D coefficient masks)
@@ -357,6 +359,144 @@ static hipError_t launch_hex8_cl(const LaunchArgs& a, const typename M::K& k) {
   if constexpr (M::HEX_CL_POINTS == 2) { if (a.opt_pf == 1) RDC_HEX8_CL(1) else RDC_HEX8_CL(2) }
   else RDC_HEX8_CL(1)
 #undef RDC_HEX8_CL
+  return hipGetLastError();
+}
+
+// ---- five unknowns: one equation row at a time ----------------------------------------------------------------------------
+// The 5 x 5 x 8 accumulator of a pair does not fit the register file (the pair kernels evaluate such models one equation row
+// at a time too, redoing the whole per-point set-up five times per pair).  Here the workgroup makes NV passes over the
+// quadrature points: in pass A the producer hands out the point records again (cheap next to the consumers' work), the
+// consumers accumulate row A only (NV x 8 accumulators), add it into an LDS image of equation row A of the cluster's nodes
+// and the image leaves as one run of NV * len doubles per node.  The image overlays the point buffers.
+template <class M, int EXP_MODE, int CW, int PW>
+__global__ void __launch_bounds__((CW + PW) * 64, 2)
+k_hex8_cl_rows(const MeshDev m, const typename M::K k, const HostPrepCl::Desc* __restrict__ desc, const HostPrepCl::Node* __restrict__ ntab,
+               const uint32_t* __restrict__ eid, const uint32_t* __restrict__ pair, const uint32_t* __restrict__ pslot,
+               const double* __restrict__ u, const double* __restrict__ aux, const double* __restrict__ elem,
+               double* __restrict__ val, double* __restrict__ rhs) {
+  constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
+  constexpr int MAXP = CW * 64, MAXE = PW * 64, MAXN = CW * 8, NT = (CW + PW) * 64, NW = CW + PW;
+  using R = Hex8Rec<M>;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int w = blockIdx.x;
+  const int tid = (int)(((threadIdx.x >> 6) + ((blockIdx.x >> 3) % NW)) % NW) * 64 + (int)(threadIdx.x & 63);
+  const HostPrepCl::Desc d = desc[w];
+  const int nimg = (int)d.row_doubles;            // image of ONE equation row: sum of NV * len
+  double* const img = lds;
+  double* const lrhs = lds + ((nimg + 1) & ~1);   // one rhs entry per owned node and pass
+  auto zero_image = [&]() {
+    v2d_t* z = reinterpret_cast<v2d_t*>(lds);
+    const v2d_t zero = {0.0, 0.0};
+    for (int x = tid; x < (((nimg + 1) & ~1) + (int)d.nown + 1) / 2; x += NT) z[x] = zero;
+  };
+  // a half-wave per node: equation row A of the node is NV * len consecutive doubles of the CSR array
+  auto copy_out = [&](int A) {
+    for (int a = tid >> 5; a < (int)d.nown; a += NT / 32) {
+      const HostPrepCl::Node nd = ntab[(size_t)w * MAXN + a];
+      const int nn = NV * (int)nd.len;
+      double* dst = val + (int64_t)(NV * NV) * nd.bptr + (int64_t)A * nn;
+      for (int x = tid & 31; x < nn; x += 32) __builtin_nontemporal_store(img[nd.off + x], dst + x);
+      if ((tid & 31) == 0) rhs[(int64_t)NV * nd.node + A] = lrhs[a];
+    }
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  if (tid >= MAXP) {
+    // ---- producer --------------------------------------------------------------------------------------------------------------
+    const int pl = tid - MAXP;
+    const uint32_t e = eid[(size_t)w * MAXE + pl];
+    const bool plive = e != 0xFFFFFFFFu;
+    double X[8][3], U[8][NV], AX[8][NA];
+    if (plive) {
+#pragma unroll
+      for (int n = 0; n < 8; n++) {
+        const int64_t I = m.conn[(int64_t)e * 8 + n];
+#pragma unroll
+        for (int c = 0; c < 3; c++) X[n][c] = m.xyz[3 * I + c];
+#pragma unroll
+        for (int v = 0; v < NV; v++) U[n][v] = u[NV * I + v];
+#pragma unroll
+        for (int v = 0; v < NA; v++) AX[n][v] = (M::NAUX > 0 && (M::AUX_LOCAL_NODE < 0 || n == M::AUX_LOCAL_NODE)) ? aux[(int64_t)M::NAUX * I + (M::NAUX > 0 ? v : 0)] : 0.0;
+      }
+    }
+    const double* ED = M::NELEM > 0 ? elem + (int64_t)e * M::NELEM : nullptr;
+#pragma unroll 1
+    for (int A = 0; A < NV; A++) {
+      if (plive) hex8_cl_produce<M>(k, X, U, AX, ED, 0, lds + pl * R::STRIDE);
+      __syncthreads();
+#pragma unroll 1
+      for (int q = 0; q < 8; q++) {
+        if (plive && q + 1 < 8) hex8_cl_produce<M>(k, X, U, AX, ED, q + 1, lds + (((q + 1) & 1) * MAXE + pl) * R::STRIDE);
+        __syncthreads();
+      }
+      zero_image();
+      lds_barrier();
+      lds_barrier();                // consumers: atomics of row A
+      copy_out(A);
+      lds_barrier();                // the image has been read: the next pass may overwrite it
+    }
+    return;
+  }
+  // ---- consumers ------------------------------------------------------------------------------------------------------------------
+  int le = 0, li = 0, na = 0;
+  const uint32_t pr = pair[(size_t)w * MAXP + tid];
+  const bool cvalid = pr != 0xFFFFFFFFu;
+  if (cvalid) { le = (int)(pr & 0xFF); li = (int)((pr >> 8) & 0xFF); na = (int)((pr >> 16) & 0xFF); }
+  uint32_t sl0 = 0, sl1 = 0;
+  int off = 0;
+  if (cvalid) {
+    sl0 = pslot[((size_t)w * MAXP + tid) * 2];
+    sl1 = pslot[((size_t)w * MAXP + tid) * 2 + 1];
+    off = (int)ntab[(size_t)w * MAXN + na].off;
+  }
+  auto pass = [&](auto tagA) {
+    constexpr int A = decltype(tagA)::value;
+    double acc[NV][8], fe = 0.0;
+#pragma unroll
+    for (int b = 0; b < NV; b++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[b][j] = 0.0;
+    __syncthreads();                // producers: point 0
+#pragma unroll 1
+    for (int q = 0; q < 8; q++) {
+      if (cvalid) hex8_cl_consume_row<M, EXP_MODE, A>(k, lds + ((q & 1) * MAXE + le) * R::STRIDE, q, li, acc, fe);
+      __syncthreads();
+    }
+    zero_image();
+    lds_barrier();
+    if (cvalid) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int s = (int)(((j < 4 ? sl0 : sl1) >> (8 * (j & 3))) & 0xFF);
+#pragma unroll
+        for (int b = 0; b < NV; b++)
+          if (hex8_cl_block<M>(A, b))   // structurally zero blocks stay the zeros of the image
+            __hip_atomic_fetch_add(img + off + NV * s + b, acc[b][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __hip_atomic_fetch_add(lrhs + na, fe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    lds_barrier();
+    copy_out(A);
+    lds_barrier();
+  };
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
+  pass(std::integral_constant<int, 2>{});
+  if constexpr (NV > 3) pass(std::integral_constant<int, (NV > 3 ? 3 : 0)>{});
+  if constexpr (NV > 4) pass(std::integral_constant<int, (NV > 4 ? 4 : 0)>{});
+}
+
+template <class M, int EXP_MODE>
+static hipError_t launch_hex8_cl_rows(const LaunchArgs& a, const typename M::K& k) {
+  constexpr int CW = 3, PW = 1;
+  if (a.cl.cw != CW || a.cl.pw != PW) return hipErrorInvalidValue;
+  const size_t points = (size_t)2 * PW * 64 * Hex8Rec<M>::STRIDE;
+  const size_t image = ((a.cl.max_row_doubles + 1) & ~(size_t)1) + (size_t)CW * 8 + 2;
+  const size_t bytes = sizeof(double) * (points > image ? points : image);
+  static bool attr = false;  // per instantiation
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_hex8_cl_rows<M, EXP_MODE, CW, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_hex8_cl_rows<M, EXP_MODE, CW, PW>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab,
+                     a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs);
   return hipGetLastError();
 }
 

@@ -17,6 +17,10 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
         // producer / consumer cluster kernel (rdc_hex8_cl.h) when the context built its lists
         if (a.cl.n_wg > 0) return launch_hex8_cl<M, EXP_MODE>(a, k);
       }
+      if constexpr (NEN == 8 && M::NV == 5) {
+        // five unknowns: the cluster kernel one equation row at a time
+        if (a.cl.n_wg > 0) return launch_hex8_cl_rows<M, EXP_MODE>(a, k);
+      }
       if constexpr (NEN == 8) {
         // node-staged form when the workgroup's row slice and node table fit 80 KB of LDS (two workgroups per CU)
         constexpr int REC = 3 + M::NV + (M::NAUX > 0 ? M::NAUX : 0);

@@ -138,7 +138,9 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
 // accumulate that row of the element matrix over the quadrature points; its producer lanes each take one ELEMENT
 // touching the cluster and evaluate the per-point data once per point for all the pairs of the element.
 struct HostPrepCl {
-  struct Limits { int max_nodes = 24, max_pairs = 192, max_elems = 64, max_row_doubles = 6000, pair_order = 1; };   // max_row_doubles: LDS image of the cluster's CSR rows
+  // max_row_doubles: LDS image of the cluster's CSR rows; img_per_block: doubles of a node block in that image (0 = nvar^2, the
+  // whole rows; nvar = one equation row at a time, as the five-unknown kernel keeps it)
+  struct Limits { int max_nodes = 24, max_pairs = 192, max_elems = 64, max_row_doubles = 6000, pair_order = 1, img_per_block = 0; };
   struct Desc {            // 16 bytes per workgroup
     uint16_t nown, npair, nelem, pad;
     uint32_t row_doubles;  // LDS image of the CSR rows of all owned nodes: sum of nvar^2 * len

@@ -19,7 +19,7 @@ cases = {
 }
 for name, (nv, p, u, aux, ed, fn) in cases.items():
     for staged in (-1, -2, 2, 0):   # -1 = cluster kernel (default for three unknowns), -2 = its persistent form, 2 = force the node-staged pair kernel, 0 = registers-resident
-        if staged < 0 and nv != 3: continue
+        if staged == -2 and nv != 3: continue   # the persistent form exists for three unknowns only
         with AssemblyContext(0) as c:
             c.set_option("hex_kernel", {-1: 0, -2: 2}.get(staged, 1))
             c.set_option("staged", max(staged, 0))
