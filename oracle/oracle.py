@@ -35,6 +35,29 @@ def lib():
     return _lib
 
 
+REF_SRC = Path("/root/reference/src/eig3.C")
+REF_LIB = HERE / "_ref" / "libref_eig3.so"
+_ref = None
+
+
+def build_ref():
+    """oracle/_ref/libref_eig3.so: the reference's own src/eig3.C compiled where it lies (oracle/Makefile) -- only where
+    /root/reference exists (this container); the GPU box uses the prebuilt file or goes without."""
+    if REF_SRC.exists():
+        src = [HERE / "ref_eig3_wrap.cpp", REF_SRC]
+        if not REF_LIB.exists() or REF_LIB.stat().st_mtime < max(p.stat().st_mtime for p in src):
+            subprocess.run(["make", "-C", str(HERE), "-B", "_ref/libref_eig3.so"], check=True, capture_output=True)
+    return REF_LIB if REF_LIB.exists() else None
+
+
+def ref_lib():
+    """the reference's eigen_decomposition behind C linkage, or None when it has not been built"""
+    global _ref
+    if _ref is None and build_ref() is not None:
+        _ref = C.CDLL(str(REF_LIB))
+    return _ref
+
+
 def fast_lib():
     """The timing build (-O3 -march=native, oracle/Makefile) for bench.py's cpu_baseline: always rebuilt on the
     machine it runs on (never shipped: -march=native code is only valid where it was compiled)."""

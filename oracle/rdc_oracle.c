@@ -10,6 +10,9 @@
  * present; no stand-in headers are written for them).  This restatement is pinned only by the
  * known-answer tests we author in tests/test_oracle_*.py (partition of unity, quadrature
  * exactness, uniform-state closed forms, finite-difference Jacobian checks, F=I limits).
+ * One exception, off the assembly path proper: the eigenvalue step of SolidSystem::post_process is pinned against the
+ * reference's own src/eig3.C, which compiles from its own source (oracle/ref_eig3_wrap.cpp, oracle/_ref,
+ * tests/test_ref_eig3.py).
  *
  * Each function cites the reference lines it follows (paths relative to the upstream tree).
  * Third-party arithmetic that is NOT in the upstream tree (libMesh d3bda6c): FIRST LAGRANGE
@@ -913,6 +916,17 @@ static void sym3_eigenvalues(const double Ain[3][3], double ev[3]) {
       }
   }
   ev[0] = a[0][0]; ev[1] = a[1][1]; ev[2] = a[2][2];
+}
+
+/* the eigenvalue step and the two stress measures of post_process, exported so that the tests can pin them against the
+ * reference's own src/eig3.C (oracle/_ref/libref_eig3.so): A9 = symmetric 3x3 row-major; ev[3] unordered */
+void oracle_stress_measures(const double* A9, double* ev, double* pressure, double* von_mises) {
+  double A[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[i][j] = A9[3 * i + j];
+  sym3_eigenvalues(A, ev);
+  *pressure = (ev[0] + ev[1] + ev[2]) / 3.0;                                                                                    /* src/solid_system.C:517 */
+  *von_mises = sqrt(ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2] - ev[0] * ev[1] - ev[0] * ev[2] - ev[1] * ev[2]);  /* :519-520 */
 }
 
 /* SolidSystem::post_process                                       src/solid_system.C:394-538

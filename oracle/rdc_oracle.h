@@ -55,6 +55,7 @@ int oracle_adpm_parcellation_integrals(int elem_type, int64_t n_elem, const uint
                                        const double* u, const rdc_adpm_ranges* r, const int32_t* elem_subdomain,
                                        const int32_t* ids, int32_t n_ids, double* out);
 void oracle_clamp_nonnegative(double* u, int64_t n);
+void oracle_stress_measures(const double* A9, double* ev, double* pressure, double* von_mises);
 int oracle_solid_post_process(int elem_type, int64_t n_elem, const uint32_t* conn, const double* xyz,
                               const double* xyz_undeformed, const double* elem_fibre, const int32_t* elem_material,
                               const rdc_solid_material* materials, double pseudo_time, double* pressure,
