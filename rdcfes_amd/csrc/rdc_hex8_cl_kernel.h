@@ -21,7 +21,7 @@ __global__ void __launch_bounds__((CW + PW) * 64, 2)
 k_hex8_cl(const MeshDev m, const typename M::K k, const HostPrepCl::Desc* __restrict__ desc, const HostPrepCl::Node* __restrict__ ntab,
           const uint32_t* __restrict__ eid, const uint32_t* __restrict__ pair, const uint32_t* __restrict__ pslot,
           const double* __restrict__ u, const double* __restrict__ aux, const double* __restrict__ elem,
-          double* __restrict__ val, double* __restrict__ rhs) {
+          double* __restrict__ val, double* __restrict__ rhs, const int diag /* "ablate" option: 64 = copy-out with 8-byte stores (timing comparison) */) {
   constexpr int NV = M::NV, NA = (M::NAUX > 0 ? M::NAUX : 1);
   constexpr int MAXP = CW * 64, MAXE = PW * 64, MAXN = CW * 8, NT = (CW + PW) * 64, NW = CW + PW;
   using R = Hex8Rec<M>;
@@ -42,13 +42,24 @@ k_hex8_cl(const MeshDev m, const typename M::K k, const HostPrepCl::Desc* __rest
     for (int x = tid; x < (((nimg + 1) & ~1) + NV * (int)d.nown + 1) / 2; x += NT) z[x] = zero;
   };
   // a half-wave per node: its NV rows are NV^2 * len consecutive doubles of the CSR array
+  // (16-byte stores: the node's image segment has the 16-byte phase of its CSR segment, rdc_prep_cl.cpp)
   auto copy_out = [&]() {
     for (int a = tid >> 5; a < (int)d.nown; a += NT / 32) {
       const HostPrepCl::Node nd = ntab[(size_t)w * MAXN + a];
-      const int nn = NV * NV * (int)nd.len;
+      const int nn = NV * NV * (int)nd.len, l32 = tid & 31;
       double* dst = val + (int64_t)(NV * NV) * nd.bptr;
-      for (int x = tid & 31; x < nn; x += 32) __builtin_nontemporal_store(img[nd.off + x], dst + x);
-      if ((tid & 31) < NV) rhs[(int64_t)NV * nd.node + (tid & 31)] = lrhs[NV * a + (tid & 31)];
+      const double* src = img + nd.off;
+      const int sh = (int)(nd.off & 1), npair = (nn - sh) >> 1;
+      const v2d_t* s2 = reinterpret_cast<const v2d_t*>(src + sh);
+      v2d_t* d2 = reinterpret_cast<v2d_t*>(dst + sh);
+      if (diag & 64) {
+        for (int x = l32; x < nn; x += 32) __builtin_nontemporal_store(src[x], dst + x);
+      } else {
+        for (int x = l32; x < npair; x += 32) __builtin_nontemporal_store(s2[x], d2 + x);
+        if (sh && l32 == 0) __builtin_nontemporal_store(src[0], dst);
+        if (((nn - sh) & 1) && l32 == 1) __builtin_nontemporal_store(src[nn - 1], dst + nn - 1);
+      }
+      if (l32 < NV) rhs[(int64_t)NV * nd.node + l32] = lrhs[NV * a + l32];
     }
   };
   // workgroup barrier that orders LDS accesses only (no wait for the global stores in flight)
@@ -354,7 +365,7 @@ static hipError_t launch_hex8_cl(const LaunchArgs& a, const typename M::K& k) {
     static bool attr = false; /* per instantiation */                                                                                  \
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_hex8_cl<M, EXP_MODE, CW, PW, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
     hipLaunchKernelGGL((k_hex8_cl<M, EXP_MODE, CW, PW, PPR>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab, \
-                       a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs);                                           \
+                       a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs, a.opt_ablate);                             \
   }
   if constexpr (M::HEX_CL_POINTS == 2) { if (a.opt_pf == 1) RDC_HEX8_CL(1) else RDC_HEX8_CL(2) }
   else RDC_HEX8_CL(1)

@@ -30,7 +30,9 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
   C.lim = lim;
   C.nvar = P.nvar;
   const int nen = P.nen;
-  const int64_t ipb = lim.img_per_block > 0 ? lim.img_per_block : (int64_t)P.nvar * P.nvar;   // image doubles per node block
+  const int64_t nv2 = (int64_t)P.nvar * P.nvar;
+  const int64_t ipb = lim.img_per_block > 0 ? lim.img_per_block : nv2;   // image doubles per node block
+  const int64_t pad = ipb == nv2 ? 1 : 0;   // whole-row images: up to one double per node to give its segment the 16-byte phase of its CSR segment
   if (nen != 8 && nen != 4) return "cluster lists: TET4 / HEX8 only";
   const int64_t n_elem = P.n_elem, n_node = P.n_node, n_owned = P.n_owned;
   if (n_owned <= 0) return "no owned nodes";
@@ -48,7 +50,7 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
   for (int64_t n = 0; n < n_owned; n++) {
     if (P.bptr[n + 1] - P.bptr[n] > 255) return "a row has more than 255 node blocks";
     if (inc_ptr[n + 1] - inc_ptr[n] > lim.max_pairs || inc_ptr[n + 1] - inc_ptr[n] > lim.max_elems) return "a node has more incident elements than a cluster may hold";
-    if (ipb * (P.bptr[n + 1] - P.bptr[n]) > lim.max_row_doubles) return "the rows of one node exceed the image budget";
+    if (ipb * (P.bptr[n + 1] - P.bptr[n]) + pad > lim.max_row_doubles) return "the rows of one node exceed the image budget";
   }
   // ---- greedy clustering ------------------------------------------------------------------------------------------
   std::vector<int32_t> cluster_of((size_t)n_owned, -1);   // -1 unassigned, -2 rejected for the cluster being grown
@@ -102,7 +104,7 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
         n_assigned++;
         assigned_update(n);
         npair += inc_ptr[n + 1] - inc_ptr[n];
-        img += ipb * (P.bptr[n + 1] - P.bptr[n]);
+        img += ipb * (P.bptr[n + 1] - P.bptr[n]) + pad;
         for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; k++) {
           const uint32_t e = inc[k];
           if (emark[e] == stamp) continue;
@@ -130,7 +132,7 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
         if (best < 0) break;
         const uint32_t c = cand[(size_t)best];
         if (npair + (inc_ptr[c + 1] - inc_ptr[c]) > lim.max_pairs || nel + new_elems(c) > lim.max_elems ||
-            img + ipb * (P.bptr[c + 1] - P.bptr[c]) > lim.max_row_doubles) {
+            img + ipb * (P.bptr[c + 1] - P.bptr[c]) + pad > lim.max_row_doubles) {
           cluster_of[c] = -2;
           rejected.push_back(c);
           continue;
@@ -174,6 +176,8 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
       const uint32_t n = cl[a];
       HostPrepCl::Node& nd = C.ntab[(size_t)w * lim.max_nodes + a];
       const int64_t len = P.bptr[n + 1] - P.bptr[n];
+      // whole-row images: the node's segment gets the 16-byte phase its CSR segment has in memory (copied out with 16-byte stores)
+      if (ipb == nv2 && ((off ^ (uint32_t)(nv2 * P.bptr[n])) & 1u)) off++;
       nd.bptr = (uint32_t)P.bptr[n]; nd.len = (uint16_t)len; nd.off = (uint16_t)off; nd.node = n;
       off += (uint32_t)(ipb * len);
     }

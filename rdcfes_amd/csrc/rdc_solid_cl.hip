@@ -35,7 +35,7 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
            const uint32_t* __restrict__ eid, const uint32_t* __restrict__ pair, const uint32_t* __restrict__ pslot,
            const double* __restrict__ Xu, const double* __restrict__ fibre, const int32_t* __restrict__ elem_material,
            const rdc_solid_material* __restrict__ materials, const double pseudo_time, double* __restrict__ val,
-           double* __restrict__ rhs, const int diag /* timing diagnostics (tools/solid_ab.py), bit mask: 1 = consumers idle, 2 = producers idle, 4 = image not zeroed, 8 = no atomics, 16 = no copy-out, 32 = no element loads */) {
+           double* __restrict__ rhs, const int diag /* timing diagnostics (tools/solid_ab.py), bit mask: 1 = consumers idle, 2 = producers idle, 4 = image not zeroed, 8 = no atomics, 16 = no copy-out, 32 = no element loads; 64 = copy-out with 8-byte stores (results unchanged) */) {
   constexpr int MAXP = CW * 64, MAXE = PW * 64, MAXN = CW * 8, NT = (CW + PW) * 64;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int w = blockIdx.x;
@@ -54,14 +54,25 @@ k_solid_cl(const MeshDev m, const HostPrepCl::Desc* __restrict__ desc, const Hos
     const cl_v2d zero = {0.0, 0.0};
     for (int x = tid; x < (((nimg + 1) & ~1) + 3 * (int)d.nown + 1) / 2; x += NT) z[x] = zero;
   };
-  // a half-wave per node: its three rows are 9 * len consecutive doubles of the CSR array
+  // a half-wave per node: its three rows are 9 * len consecutive doubles of the CSR array, written with 16-byte stores (the
+  // node's image segment has the 16-byte phase of its CSR segment: rdc_prep_cl.cpp)
   auto copy_out = [&]() {
     for (int a = tid >> 5; a < (int)d.nown; a += NT / 32) {
       const HostPrepCl::Node nd = ntab[(size_t)w * MAXN + a];
-      const int n9 = 9 * (int)nd.len;
+      const int n9 = 9 * (int)nd.len, l32 = tid & 31;
       double* dst = val + 9 * (int64_t)nd.bptr;
-      for (int k = tid & 31; k < n9; k += 32) __builtin_nontemporal_store(img[nd.off + k], dst + k);
-      if ((tid & 31) < 3) rhs[3 * (int64_t)nd.node + (tid & 31)] = lrhs[3 * a + (tid & 31)];
+      const double* src = img + nd.off;
+      const int sh = (int)(nd.off & 1), npair = (n9 - sh) >> 1;
+      const cl_v2d* s2 = reinterpret_cast<const cl_v2d*>(src + sh);
+      cl_v2d* d2 = reinterpret_cast<cl_v2d*>(dst + sh);
+      if (diag & 64) {   // 8-byte stores (timing comparison; same values)
+        for (int k = l32; k < n9; k += 32) __builtin_nontemporal_store(src[k], dst + k);
+      } else {
+        for (int k = l32; k < npair; k += 32) __builtin_nontemporal_store(s2[k], d2 + k);
+        if (sh && l32 == 0) __builtin_nontemporal_store(src[0], dst);
+        if (((n9 - sh) & 1) && l32 == 1) __builtin_nontemporal_store(src[n9 - 1], dst + n9 - 1);
+      }
+      if (l32 < 3) rhs[3 * (int64_t)nd.node + l32] = lrhs[3 * a + l32];
     }
   };
   // workgroup barrier that orders LDS accesses only (no wait for the global stores in flight)

@@ -333,6 +333,7 @@ int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubl
     for (int a = 0; a < d.nown; a++) {
       const HostPrepCl::Node& nd = C.ntab[w * lim.max_nodes + a];
       if ((int64_t)nd.node >= g_prep.n_owned || seen[nd.node]++) { g_err = "node listed twice"; return 3; }
+      if ((off ^ (uint32_t)(g_prep.nvar * g_prep.nvar * g_prep.bptr[nd.node])) & 1u) off++;   // the segment has the 16-byte phase of its CSR segment
       if (nd.bptr != (uint32_t)g_prep.bptr[nd.node] || nd.len != g_prep.bptr[nd.node + 1] - g_prep.bptr[nd.node] || nd.off != off) { g_err = "node table"; return 4; }
       off += (uint32_t)(g_prep.nvar * g_prep.nvar * nd.len);
     }

@@ -50,7 +50,7 @@ def test_cluster_lists_on_a_ghosted_partition(shim):
 def test_cluster_lists_tiny_limits(shim):
     """limits so tight that clusters are single nodes still give complete, consistent lists"""
     conn, xyz = synth.hex_mesh(4, jitter=0.0)
-    st = _build(shim, 8, conn, xyz.shape[0], xyz.shape[0], (1, 8, 8, 243))
+    st = _build(shim, 8, conn, xyz.shape[0], xyz.shape[0], (1, 8, 8, 244))   # 27 blocks x 9 + the phase double
     assert st["n_wg"] == xyz.shape[0] and st["largest"] == 1
 
 

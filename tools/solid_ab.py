@@ -25,7 +25,7 @@ with AssemblyContext(0) as c:
                          ("fused, consumers idle", {"solid_store": 1}), ("fused, producers idle", {"solid_store": 2}), ("fused, no compute", {"solid_store": 3}),
                          ("fused, no compute, no atomics", {"solid_store": 11}), ("fused, no compute, no copy-out", {"solid_store": 19}),
                          ("fused, no compute, no element loads", {"solid_store": 35}), ("fused, barriers + lists only", {"solid_store": 63}),
-                         ("fused, compute only", {"solid_store": 28}))):
+                         ("fused, compute only", {"solid_store": 28}), ("fused, copy-out with 8-byte stores", {"solid_store": 64}))):
         if sel is not None and idx not in sel: continue
         c.set_option("solid_store", 0); c.set_option("solid_split", 1); c.set_option("solid_gather", 0); c.set_option("solid_kernel", 0); c.set_option("solid_cl_waves", 31); c.set_option("solid_cl_order", 1)
         for k, v in opts.items(): c.set_option(k, v)
