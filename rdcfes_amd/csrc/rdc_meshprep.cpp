@@ -362,6 +362,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
         std::vector<int> new_idx((size_t)np_w);
         std::vector<std::array<int, 4>> col_of((size_t)np_w);  // rotated column j -> original local index
         std::vector<int> copy_of((size_t)np_w, 0);
+        bool wg_fail = false;   // this workgroup's schedule does not fit: nothing of it is written (the mesh falls back to the generic kernels)
         if (nen == 4 && conflict_aware) {
           std::vector<int> lanes_used((size_t)NW, 0);
           std::vector<std::array<std::array<uint8_t, 32>, 3>> bank((size_t)NW);
@@ -395,7 +396,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
                 if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_w = wv; best_q = q; }
               }
             }
-            if (best_w < 0) { fail_flag = 1; best_w = 0; }
+            if (best_w < 0) { wg_fail = true; break; }   // no wave can take the pair (a node with more pairs than NW * copies lanes)
             new_idx[idx] = lanes_used[best_w] * NW + best_w;
             copy_of[idx] = node_in_wave[(size_t)best_w * (n1 - n0) + (I - n0)]++;
             lanes_used[best_w]++;
@@ -408,7 +409,7 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
             }
           }
           for (int wv = 0; wv < NW; wv++)
-            if (lanes_used[wv] * NW + wv - NW >= block) fail_flag = 1;
+            if (lanes_used[wv] * NW + wv - NW >= block) wg_fail = true;
         } else {
           for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {
             const int idx = (int)(p - inc_ptr[n0]);
@@ -417,6 +418,11 @@ std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned,
             copy_of[idx] = (idx / NW) % NCOP;
             for (int j = 0; j < nen && j < 4; j++) col_of[idx][j] = (nen == 4) ? (j ^ i) : 0;
           }
+        }
+        if (wg_fail) {
+#pragma omp atomic write
+          fail_flag = 1;
+          continue;
         }
         // pair records and contribution entries in ascending pair order -> fixed summation order
         for (int64_t p = inc_ptr[n0]; p < inc_ptr[n1]; p++) {

@@ -55,6 +55,9 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
     std::vector<int32_t> free_nb((size_t)n_owned, 0);
     int max_nb = 0;
     for (int64_t n = 0; n < n_owned; n++) {
+      // the moment slice holds NBP / MAXN = 16 node blocks per row: a node of higher valence cannot be placed -- reject the
+      // mesh before any list is written (the caller falls back to the pair kernels)
+      if (P.bptr[n + 1] - P.bptr[n] > NBP / MAXN) return "a node has more than 16 node blocks in its row (valence > 15): no element-visit lists";
       int c = 0;
       for (int64_t b = P.bptr[n]; b < P.bptr[n + 1]; b++) c += (P.bcol[b] != (int32_t)n && (int64_t)P.bcol[b] < n_owned);
       free_nb[n] = c;
@@ -178,7 +181,10 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
     for (uint32_t m : t) if (!((int64_t)m < n_owned && cluster_of[m] == (int32_t)w)) ordered.push_back(m);
     t.swap(ordered);
     ntouch_w[(size_t)w] = (int32_t)t.size();
-    if (t.size() > 255 || vis.size() > (size_t)BLOCK) fail = 1;
+    if (t.size() > 255 || vis.size() > (size_t)BLOCK) {
+#pragma omp atomic write
+      fail = 1;
+    }
   }
   if (fail) return "internal: cluster limits violated";
   int mx = 1;
@@ -197,6 +203,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
     const std::vector<uint32_t>& t = touched[(size_t)w];
     const std::vector<uint32_t>& vis = visits[(size_t)w];
     HostPrepEv::Desc& d = E.desc[(size_t)w];
+    bool wfail = false;
     d.nown = (uint32_t)cl.size(); d.nvis = (uint32_t)vis.size(); d.ntouch = (uint32_t)t.size(); d.pad = 0;
     d.min_node = *std::min_element(cl.begin(), cl.end());
     d.max_node = *std::max_element(cl.begin(), cl.end());
@@ -214,9 +221,14 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       nd.obase = ob;
       ob += (uint32_t)(nv2 * (size_t)len);
       blk += (uint32_t)len;
-      if (len > NBP / MAXN) fail = 1;
+      if (len > NBP / MAXN) wfail = true;
     }
     d.nb = blk;
+    if (wfail) {   // a row does not fit the slice: write nothing more for this workgroup (checked up front; kept as a guard)
+#pragma omp atomic write
+      fail = 1;
+      continue;
+    }
     // mirror blocks: block (x, slot s) whose column node is cluster node x2 != x <-> block (x2, slot of node x in the row of x2)
     {
       uint8_t* bp = &E.bpart[(size_t)w * NBP];
@@ -230,7 +242,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
           const int32_t* row2 = &P.bcol[P.bptr[c2]];
           const int64_t len2 = P.bptr[c2 + 1] - P.bptr[c2];
           const int64_t s2 = std::find(row2, row2 + len2, (int32_t)n) - row2;
-          if (s2 >= len2) { fail = 1; continue; }   // the node graph is symmetric
+          if (s2 >= len2) { wfail = true; continue; }   // the node graph is symmetric
           bp[(size_t)(b - P.bptr[n]) * MAXN + x] = (uint8_t)(s2 * MAXN + (int64_t)x2);
         }
       }
@@ -319,7 +331,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
           if (cost < best_cost) { best_cost = cost; best_g = g; best_q = q; }
         }
       }
-      if (best_g < 0) { fail = 1; break; }
+      if (best_g < 0) { wfail = true; break; }
       conf_w[(size_t)w] += best_cost / 1000;   // rows whose node already sits at the same vertex position of their 16-lane group
       int pm[4];
       perm_of(v.r, best_q, pm);
@@ -343,10 +355,14 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
         for (int j = 0; j < 4; j++)
           word |= (uint32_t)P.eslot[(size_t)v.e * 16 + (size_t)perm[i] * 4 + (size_t)perm[j]] << (8 * j);
         E.vslot[((size_t)w * BLOCK + lane) * 4 + (size_t)i] = word;
-        if (li[i] >= cl.size()) fail = 1;
+        if (li[i] >= cl.size()) wfail = true;
       }
     }
     for (int g = 0; g < 16; g++) pass_w[(size_t)w] += maxr_g[g];
+    if (wfail) {
+#pragma omp atomic write
+      fail = 1;
+    }
   }
   if (fail) return "internal: element-visit list construction failed";
   for (int64_t w = 0; w < nwg; w++) {

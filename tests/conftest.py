@@ -42,6 +42,12 @@ def oracle():
 
 def build_shim():
     """g++ build of the product's host/device headers (tests/host_shim.cpp)."""
+    if os.environ.get("RDC_SHIM_SO"):      # e.g. the AddressSanitizer build of tools/asan_prep.sh
+        lib = C.CDLL(str(ROOT / os.environ["RDC_SHIM_SO"]))
+        lib.shim_prep_size.restype = C.c_int64
+        lib.shim_prep_size.argtypes = [C.c_int]
+        lib.shim_prep_error.restype = C.c_char_p
+        return lib
     bdir = ROOT / "tests" / "_build"
     bdir.mkdir(exist_ok=True)
     so = bdir / "libhost_shim.so"

@@ -501,6 +501,10 @@ int64_t shim_prep_size(int what) {
     case 16: return (int64_t)(g_prep.sdesc.size() * sizeof(HostPrep::StoreDesc));
     case 17: return (int64_t)g_prep.contrib.size();
     case 20: return (int64_t)g_gather.gptr.size();
+    case 30: return (int64_t)g_ev.vloc.size();
+    case 31: return (int64_t)(g_ev.desc.size() * sizeof(HostPrepEv::Desc));
+    case 32: return (int64_t)g_ev.n_group_rows;
+    case 33: return (int64_t)g_ev.n_conflicts;
     case 21: return (int64_t)g_gather.gsrc.size();
     case 22: return (int64_t)g_gather.brow.size();
     case 100: return g_prep.n_colours;
@@ -535,6 +539,8 @@ int shim_prep_copy(int what, void* dst) {
     case 17: CP(contrib);
   }
 #undef CP
+  if (what == 30) { std::memcpy(dst, g_ev.vloc.data(), g_ev.vloc.size() * 4); return 0; }
+  if (what == 31) { std::memcpy(dst, g_ev.desc.data(), g_ev.desc.size() * sizeof(HostPrepEv::Desc)); return 0; }
 #define CG(v) std::memcpy(dst, g_gather.v.data(), g_gather.v.size() * sizeof(g_gather.v[0])); return 0
   switch (what) {
     case 20: CG(gptr);
