@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RDC_ABI_VERSION 1
+#define RDC_ABI_VERSION 3   /* 2: round-2 additions (solid post-process, ADPM/PROTEAS, chunked hand-back); 3: per-part entry points, part-1 bound recorded by the call */
 
 /* status codes */
 #define RDC_OK               0
@@ -270,8 +270,10 @@ int rdc_csr_download(rdc_ctx* ctx, double* val, double* rhs);
  * the copies are only enqueued on the context's stream (use pinned host memory; complete after rdc_synchronize or an
  * event of the caller) -- so the rows of part 1 of a two-part assembly can travel while part 2 is still computing. */
 int rdc_csr_download_rows(rdc_ctx* ctx, int64_t node_begin, int64_t node_end, double* val, double* rhs, int async);
-/* two-part assembly: the rows of nodes [0, *n_nodes) are the ones "part" = 1 writes with the current
- * "interior_nodes" (whole workgroups inside the interior; 0 when the active path cannot launch sub-ranges) */
+/* two-part assembly: the rows of nodes [0, *n_nodes) are complete after "part" = 1 (whole workgroups inside the
+ * interior; 0 when the active kernel path cannot launch sub-ranges).  After a part-1 assemble call the value is what
+ * THAT call completed -- the kernel path, and with it the split, depends on the model, the parameter values and the
+ * tuning options; before any part-1 call since the upload it is the prediction for the default path. */
 int rdc_part1_nodes(const rdc_ctx* ctx, int64_t* n_nodes);
 
 /* ---- post-solve nodal kernel: negativity clamp of check_solution,

@@ -65,6 +65,12 @@ SIGNATURES = {
 }
 
 
+def header_abi_version() -> int:
+    import re
+    h = (Path(__file__).resolve().parent.parent / "include" / "rdc_assembly.h").read_text()
+    return int(re.search(r"#define\s+RDC_ABI_VERSION\s+(\d+)", h).group(1))
+
+
 def load():
     """Load librdc_assembly.so and bind every declared symbol; raises if anything is missing."""
     global _lib
@@ -75,6 +81,12 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m rdcfes_amd.build` "
             "(the assembly path is HIP-only; there is no CPU fallback)")
     lib = C.CDLL(str(LIB_PATH))
+    # version first: an older .so then fails with a version message, not with a missing-symbol AttributeError
+    lib.rdc_abi_version.restype = C.c_int
+    want, have = header_abi_version(), lib.rdc_abi_version()
+    if have != want:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {have}, include/rdc_assembly.h declares {want}: rebuild it "
+                           "(`python -m rdcfes_amd.build --force`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res

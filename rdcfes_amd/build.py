@@ -41,6 +41,7 @@ ARCH = os.environ.get("RDC_OFFLOAD_ARCH", "gfx950")
 CXXFLAGS = [
     "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics",
     "-fopenmp", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-pass-failed",
+    "-Wno-inline-asm",   # "clobber list contains reserved registers: m0": the LDS-DMA asm sets m0 itself, on purpose
     "-ffp-contract=fast",
 ]
 # experiments only: extra compiler flags for every HIP source, e.g. RDC_EXTRA_HIPCC_FLAGS="-mllvm -amdgpu-enable-max-ilp-scheduling-strategy=1"
@@ -99,9 +100,20 @@ def _compile(src: str, extra=()):
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     res = _parse_resources(r.stderr) if hip else {}
-    rest = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln and not ln.lstrip().startswith(("|", "^")) and "__launch_bounds__" not in ln)
-    if rest.strip() and os.environ.get("RDC_BUILD_VERBOSE"):
-        sys.stderr.write(rest + "\n")
+    # everything that is not a kernel-resource-usage remark (= genuine warnings, with their source excerpts) reaches the log
+    keep, skip = [], 0
+    for ln in r.stderr.splitlines():
+        if "kernel-resource-usage" in ln and "remark:" in ln:
+            skip = 2          # the remark's source excerpt: the quoted line and its caret line
+            continue
+        if skip and ln.lstrip().startswith(("|", "^")) or (skip and "__launch_bounds__" in ln) or (skip and "__global__" in ln):
+            skip -= 1
+            continue
+        skip = 0
+        if ln.strip() and not ln.strip().endswith("remarks generated.") and "warnings generated" not in ln:
+            keep.append(ln)
+    if keep:
+        sys.stderr.write(f"[rdcfes_amd.build] {src}:\n" + "\n".join(keep) + "\n")
     return obj, res
 
 
@@ -124,6 +136,19 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     import json
     RESOURCES.write_text(json.dumps(resources, indent=0, sort_keys=True))
+    # spills / scratch are performance bugs on this path: always say so.  The kernels every default configuration runs
+    # are listed by name; the experimental / diagnostic instantiations are counted (full list: lib/kernel_resources.json,
+    # RDC_BUILD_VERBOSE=1).  RDC_BUILD_STRICT=1 turns scratch in a default-path kernel into an error.
+    default_path = ("k_tet4_ev", "k_tet4_evm", "k_tet4_evc", "k_tet4_rg5", "k_hex8_cl", "k_solid_cl", "k_pack_nodes")
+    bad = {k: v for k, v in resources.items() if v.get("scratch_bytes_per_lane", 0) or v.get("vgpr_spills", 0)}
+    hot = {k: v for k, v in bad.items() if any(f"{len(n)}{n}I" in k or f"{len(n)}{n}E" in k for n in default_path)}
+    for k, v in sorted(bad.items() if os.environ.get("RDC_BUILD_VERBOSE") else hot.items()):
+        sys.stderr.write(f"[rdcfes_amd.build] scratch: {k}: {v.get('scratch_bytes_per_lane', 0)} B/lane, {v.get('vgpr_spills', 0)} VGPR spills, "
+                         f"{v.get('vgprs')} VGPRs\n")
+    if bad:
+        sys.stderr.write(f"[rdcfes_amd.build] {len(bad)} of {len(resources)} kernel instantiations use scratch ({len(hot)} on a default path)\n")
+    if hot and os.environ.get("RDC_BUILD_STRICT"):
+        raise RuntimeError(f"{len(hot)} default-path kernels use scratch memory")
     if verbose:
         print(f"[rdcfes_amd.build] built {LIB}", flush=True)
     return LIB

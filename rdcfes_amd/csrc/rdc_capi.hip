@@ -55,6 +55,7 @@ struct rdc_ctx {
   bool ev_tried = false;           // the element-visit lists of this mesh have been built (or found impossible)
   int64_t ev_perm_interior = -2;   // "interior_nodes" value the uploaded workgroup order was built for
   int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
+  int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
   int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
   int opt_ev_lds = 54000;          // LDS bytes per workgroup the clusters are sized for (3 workgroups per CU)
@@ -273,6 +274,15 @@ int ev_order_for_interior(rdc_ctx* c) {
 }
 
 // two-part assembly: number of leading row-gather workgroups whose nodes all lie inside [0, interior_nodes)
+// element-visit lists: clusters are not node ranges; the rows of [0, n) are complete after part 1 when no cluster with a
+// node below n reaches up to "interior_nodes"
+int64_t ev_part1_node_bound(const rdc_ctx* c) {
+  int64_t n = c->opt_interior;
+  for (const HostPrepEv::Desc& d : c->prep_ev.desc)
+    if (!((int64_t)d.max_node < c->opt_interior)) n = std::min<int64_t>(n, (int64_t)d.min_node);
+  return n < 0 ? 0 : n;
+}
+
 int part1_workgroups(const rdc_ctx* c) {
   int lo = 0, hi = (int)c->prep.wg2.size();
   while (lo < hi) {
@@ -464,7 +474,9 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.ev.wg_perm = (const uint32_t*)c->ev_perm.p;
     if (c->opt_part == 1) {
       c->part1_packed = false;
+      c->part1_nodes = 0;
       if (c->ev_part1_wg == 0) return RDC_OK;
+      c->part1_nodes = ev_part1_node_bound(c);
       a.ev.wg_begin = 0; a.ev.wg_count = c->ev_part1_wg;
       if (!c->pack_event) RDC_HIP(c, hipEventCreateWithFlags(&c->pack_event, hipEventDisableTiming));
       a.pack_part = 1; a.pack_event = c->pack_event;
@@ -485,7 +497,9 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     const int split = sub ? part1_workgroups(c) : 0;
     if (c->opt_part == 1) {
       c->part1_packed = false;
+      c->part1_nodes = 0;
       if (!sub || split == 0) return RDC_OK;
+      c->part1_nodes = (int64_t)c->prep.wg2[(size_t)split - 1].n0 + c->prep.wg2[(size_t)split - 1].nnodes;
       a.rg2.wg_begin = 0; a.rg2.wg_count = split;
       // part 1 packs the records of the owned nodes only and part 2 those of the ghosts, ordered by an event: the two
       // parts may run on different streams (rdc_assembly.h, stream contract of the two-part assembly)
@@ -561,9 +575,10 @@ int rdc_ctx_create(int device_ordinal, rdc_ctx** out) {
     return fail(nullptr, RDC_ERR_HIP, "device initialisation failed: %s", hipGetErrorString(e));
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.sharedMemPerBlock > 0)
-    c->max_lds = prop.sharedMemPerBlock;
-    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) {
+    if (prop.sharedMemPerBlock > 0) c->max_lds = prop.sharedMemPerBlock;
+    if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  }
   *out = c;
   return RDC_OK;
 }
@@ -715,6 +730,7 @@ int rdc_mesh_upload(rdc_ctx* c, int elem_type, int64_t n_elem, int64_t n_node, i
     }
   }
   c->prep_ev = HostPrepEv();
+  c->part1_nodes = -1;
   c->ev_perm_interior = -2;
   c->ev_tried = false;
   if (elem_type == RDC_TET4 && nvar == 5 && P.rg2_ok) {
@@ -1032,13 +1048,12 @@ int rdc_part1_nodes(const rdc_ctx* c, int64_t* n_nodes) {
   if (!c || !n_nodes) return RDC_ERR_INVALID;
   if (!c->have_mesh) return RDC_ERR_STATE;
   *n_nodes = 0;
+  // after a part-1 call: what THAT call completed (the kernel path depends on the model, the parameter values and the
+  // tuning options, and the paths split the rows differently)
+  if (c->part1_nodes >= 0) { *n_nodes = c->part1_nodes; return RDC_OK; }
+  // before any part-1 call: the prediction for the default path of the shipped-pattern PIHNA (element-visit clusters)
   if (c->opt_interior >= 0 && c->prep_ev.ok && (c->opt_kernel == 0 || c->opt_kernel == 7)) {
-    // element-visit lists: clusters are not node ranges; the rows of [0, n) are complete after part 1 when no cluster
-    // with a node below n reaches up to "interior_nodes"
-    int64_t n = c->opt_interior;
-    for (const HostPrepEv::Desc& d : c->prep_ev.desc)
-      if (!((int64_t)d.max_node < c->opt_interior)) n = std::min<int64_t>(n, (int64_t)d.min_node);
-    *n_nodes = n;
+    *n_nodes = ev_part1_node_bound(c);
     return RDC_OK;
   }
   if (c->opt_interior < 0 || !c->prep.rg2_ok || c->prep.nen != 4 || c->prep.wg2.empty()) return RDC_OK;

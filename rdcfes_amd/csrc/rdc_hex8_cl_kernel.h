@@ -351,8 +351,8 @@ static hipError_t launch_hex8_cl(const LaunchArgs& a, const typename M::K& k) {
   if (a.cl.cw != CW || a.cl.pw != PW) return hipErrorInvalidValue;
   const size_t pbytes = hex8_clp_lds_bytes<M>(CW, PW, a.cl.max_row_doubles);
   if (a.cl.grid > 0 && pbytes <= 80 * 1024) {   // persistent form: two workgroups per CU must fit
-    static bool pattr = false;  // per instantiation
-    if (!pattr) { (void)hipFuncSetAttribute((const void*)k_hex8_clp<M, EXP_MODE, CW, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); pattr = true; }
+    static std::atomic<uint64_t> pattr[1];  /* per instantiation and device */
+    dyn_lds_once(pattr[0], (const void*)k_hex8_clp<M, EXP_MODE, CW, PW>, 80 * 1024);
     const int grid = a.cl.grid < a.cl.n_wg ? a.cl.grid : a.cl.n_wg;
     hipLaunchKernelGGL((k_hex8_clp<M, EXP_MODE, CW, PW>), dim3(grid), dim3((CW + PW) * 64), pbytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab,
                        a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs, a.cl.n_wg, (int)((a.cl.max_row_doubles + 1) & ~(size_t)1), a.opt_ablate);
@@ -362,8 +362,8 @@ static hipError_t launch_hex8_cl(const LaunchArgs& a, const typename M::K& k) {
 #define RDC_HEX8_CL(PPR)                                                                                                              \
   {                                                                                                                                   \
     const size_t bytes = hex8_cl_lds_bytes<M>(CW, PW, a.cl.max_row_doubles, PPR);                                                     \
-    static bool attr = false; /* per instantiation */                                                                                  \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_hex8_cl<M, EXP_MODE, CW, PW, PPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+    static std::atomic<uint64_t> attr[1];  /* per instantiation and device */ \
+    dyn_lds_once(attr[0], (const void*)k_hex8_cl<M, EXP_MODE, CW, PW, PPR>, 80 * 1024); \
     hipLaunchKernelGGL((k_hex8_cl<M, EXP_MODE, CW, PW, PPR>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab, \
                        a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs, a.opt_ablate);                             \
   }
@@ -504,8 +504,8 @@ static hipError_t launch_hex8_cl_rows(const LaunchArgs& a, const typename M::K& 
   const size_t points = (size_t)2 * PW * 64 * Hex8Rec<M>::STRIDE;
   const size_t image = ((a.cl.max_row_doubles + 1) & ~(size_t)1) + (size_t)CW * 8 + 2;
   const size_t bytes = sizeof(double) * (points > image ? points : image);
-  static bool attr = false;  // per instantiation
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_hex8_cl_rows<M, EXP_MODE, CW, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
+  static std::atomic<uint64_t> attr[1];  /* per instantiation and device */
+    dyn_lds_once(attr[0], (const void*)k_hex8_cl_rows<M, EXP_MODE, CW, PW>, 80 * 1024);
   hipLaunchKernelGGL((k_hex8_cl_rows<M, EXP_MODE, CW, PW>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, k, a.cl.desc, a.cl.ntab,
                      a.cl.eid, a.cl.pair, a.cl.pslot, a.u, a.aux, a.elem, a.val, a.rhs);
   return hipGetLastError();

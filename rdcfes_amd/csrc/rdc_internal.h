@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -13,6 +14,17 @@
 #include "rdc_prep.h"
 
 namespace rdc {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set it once per (kernel instantiation, device
+// ordinal) -- a process may hold contexts on several ordinals (rdc_device_count / rdc_ctx_create).
+inline void dyn_lds_once(std::atomic<uint64_t>& done, const void* fn, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = dev >= 0 && dev < 64 ? (1ull << dev) : 0;
+  if (bit && (done.load(std::memory_order_relaxed) & bit)) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (bit) done.fetch_or(bit, std::memory_order_relaxed);
+}
 
 // device view of the staged row-gather work lists (HostPrep::wg2 ...)
 struct Rg2Dev {

@@ -28,12 +28,8 @@ static hipError_t launch_rd_impl(const LaunchArgs& a, const typename M::K& k) {
         const size_t staged_bytes = sizeof(double) * (tab_off + (size_t)a.hx_max_nodes * REC);
         // opt_staged: 1 = where the model profits (M::HEX_STAGED), 2 = always, 0 = never
         if ((a.opt_staged == 2 || (a.opt_staged == 1 && M::HEX_STAGED)) && a.hx_ploc && staged_bytes <= 80 * 1024) {
-          static bool attr_set = false;  // per instantiation
-          if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_rowgather_staged<M, NEN, EXP_MODE, BLOCK>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            attr_set = true;
-          }
+          static std::atomic<uint64_t> attr_set[1];  /* per instantiation and device */
+    dyn_lds_once(attr_set[0], (const void*)k_rowgather_staged<M, NEN, EXP_MODE, BLOCK>, 80 * 1024);
           hipLaunchKernelGGL((k_rowgather_staged<M, NEN, EXP_MODE, BLOCK>), dim3(a.n_wg), dim3(BLOCK), staged_bytes, a.stream,
                              a.m, k, a.u, a.aux, a.elem, a.hx_nl_ptr, a.hx_nlist, a.hx_ploc, (int)tab_off, a.val, a.rhs);
           return hipGetLastError();

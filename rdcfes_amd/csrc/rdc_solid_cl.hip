@@ -309,13 +309,13 @@ template <int CW, int PW>
 static hipError_t launch_cl(const SolidArgs& a) {
   const size_t bytes = solid_cl_lds_bytes(CW, PW, a.cl.max_row_doubles);
   if (a.params.use_symmetry) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_solid_cl<CW, PW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static std::atomic<uint64_t> attr[1];  /* per instantiation and device */
+    dyn_lds_once(attr[0], (const void*)k_solid_cl<CW, PW, true>, 160 * 1024);
     hipLaunchKernelGGL((k_solid_cl<CW, PW, true>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, a.cl.desc, a.cl.ntab, a.cl.eid,
                        a.cl.pair, a.cl.pslot, a.Xu, a.fibre, a.elem_material, a.materials, a.params.pseudo_time, a.val, a.rhs, a.store_mode);
   } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_solid_cl<CW, PW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static std::atomic<uint64_t> attr[1];  /* per instantiation and device */
+    dyn_lds_once(attr[0], (const void*)k_solid_cl<CW, PW, false>, 160 * 1024);
     hipLaunchKernelGGL((k_solid_cl<CW, PW, false>), dim3(a.cl.n_wg), dim3((CW + PW) * 64), bytes, a.stream, a.m, a.cl.desc, a.cl.ntab, a.cl.eid,
                        a.cl.pair, a.cl.pslot, a.Xu, a.fibre, a.elem_material, a.materials, a.params.pseudo_time, a.val, a.rhs, a.store_mode);
   }

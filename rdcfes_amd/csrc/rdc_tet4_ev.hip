@@ -193,8 +193,6 @@ k_tet4_evp(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
   constexpr int BLOCK = 256, NP = 4;
   constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [main: M | R, later the CSR image][records x 2][lists x 2]
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* glb_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wv == 3;
@@ -374,12 +372,9 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
     const size_t accd = (size_t)ev::NM * ev::NBP + 5 * ev::MAXN;
     const size_t main_doubles = ((accd > E.max_out_doubles ? accd : E.max_out_doubles) + 1) & ~(size_t)1;
     const size_t bytes = (main_doubles + (size_t)2 * 4 * E.nls * 2) * sizeof(double) + 2 * EvpLists::BYTES;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)k_tet4_evp<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_tet4_evp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
+    static std::atomic<uint64_t> attr[2];  /* per instantiation and device */
+    dyn_lds_once(attr[0], (const void*)k_tet4_evp<3>, 160 * 1024);
+    dyn_lds_once(attr[1], (const void*)k_tet4_evp<0>, 160 * 1024);
     if (a.exp_mode == 3)
       hipLaunchKernelGGL((k_tet4_evp<3>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, E.wg_perm, k,
                          a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, (int)main_doubles, a.opt_ablate);

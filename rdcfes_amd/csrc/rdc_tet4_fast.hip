@@ -128,7 +128,7 @@ k_tet4_rowgather(const MeshDev m, const typename M::K k, const double* __restric
     sink.row = lds + (int)(NV * NV * (b0 - bb0));
     sink.lrhs = lrhs + (int)(I - n0) * NV;
     if (ABL < 2) tet4_row0<M, EXP_MODE>(k, X, U, AX, sink);
-    else sink.dummy = X[0][0] + X[1][1] + X[2][2] + X[3][0] + U[0][0] + U[1][1] + U[2][2] + U[3][3] + sink.off[0] +
+    else sink.dummy = X[0][0] + X[1][1] + X[2][2] + X[3][0] + U[0][0] + U[1][1] + U[2][2] + U[3][NV - 1] + sink.off[0] +
                       sink.off[1] + sink.off[2] + sink.off[3];
     if (ABL != 0) sink.row[sink.stride + (threadIdx.x & 3)] = sink.dummy;  // keep the work alive
   }
@@ -339,7 +339,7 @@ k_tet4_rg5(const HostPrep::WgDesc* __restrict__ desc, const uint32_t* __restrict
   // The row slice starts one double into LDS when its first CSR value sits at an odd index, so that LDS and global
   // memory have the same 16-byte phase and the store phase can move 16 bytes per lane; the private diagonal
   // accumulators follow at the next even index (16-byte reads in the fold).
-  const int nval = d.nb * NV * NV, sh = (int)(d.vb0 & 1), dbase = (nval + sh + 1) & ~1, ntot = dbase + NDV * ns;
+  const int nval = d.nb * NV * NV, sh = (int)(d.vb0 & 1), dbase = (nval + sh + 1) & ~1;
   double* const sl = lds + sh;
   if (STAMP) tx[1] = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed ...

@@ -636,3 +636,44 @@ def test_two_part_assembly_on_two_streams(oracle):
             _, _, val0, rhs0 = oracle.assemble(0, 4, lp.conn, lp.xyz, 5, p, u_old=exp_u, n_owned=lp.n_owned)
             assert np.isfinite(val).all() and np.isfinite(rhs).all()
             assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params,opts", [("shipped", {}), ("full", {}), ("shipped", {"slim": 1}), ("shipped", {"kernel": 5}),
+                                         ("shipped", {"specialise": 0})])
+def test_chunked_handback_follows_the_part1_bound(params, opts):
+    """rdc_part1_nodes after a part-1 call = the rows THAT call completed, whatever kernel path the parameters and options
+    select (element-visit clusters, pair workgroups, or nothing): rows [0, n1) downloaded between the parts plus rows
+    [n1, n_owned) after part 2 give the whole assembly (the bound used to be predicted from the
+    element-visit lists alone)."""
+    conn, xyz = synth.kuhn_tet_mesh(12, order="lex")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict(params))
+    nn = xyz.shape[0]
+    n_int = int(0.6 * nn)
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("interior_nodes", n_int)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val0, rhs0 = ctx.csr_download()
+        ctx.field_upload(FIELD_OLD_SOLUTION, 0.5 * u)      # every row now holds something else
+        ctx.assemble_pihna(p)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        val = np.full_like(val0, np.nan)
+        rhs = np.full_like(rhs0, np.nan)
+        ctx.set_option("part", 1)
+        ctx.assemble_pihna(p)
+        n1 = ctx.part1_nodes()
+        assert 0 <= n1 <= n_int
+        ctx.csr_download_rows(0, n1, val.ctypes.data, rhs.ctypes.data)
+        ctx.set_option("part", 2)
+        ctx.assemble_pihna(p)
+        ctx.csr_download_rows(n1, nn, val.ctypes.data, rhs.ctypes.data)
+        ctx.set_option("part", 0)
+    assert np.isfinite(val).all() and np.isfinite(rhs).all()
+    assert rel(val, val0) < 1e-13 and rel(rhs, rhs0) < 1e-13
+    if not opts and params == "shipped":
+        assert n1 > 0.3 * n_int                             # the default path does split
