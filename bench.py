@@ -16,7 +16,9 @@ Prints ONE JSON line on rank 0.  At N = 1 the line also carries
                  kernel on K(119), each timed here with HIP events (3 warm-ups + 10 launches);
   "handback"     the CSR hand-back to the host (SURVEY §8d "kernel + CSR-handback separately"): D2H of values + rhs
                  into pinned memory, alone, behind the kernel, and overlapped with part 2 of a two-part assembly;
-  "cpu_baseline" the oracle (a port of the reference loop) on 1 and on all host cores.
+  "cpu_baseline" the oracle (a port of the reference loop) on the benchmark mesh itself with all host cores (+ 1 core on a sample);
+  "parity"       relative residual of the timed configuration's GPU result (rhs L2, matrix Frobenius) against that CPU assembly;
+  "value_with_handback"  elements per second when the CSR is downloaded to the host every step (never `value`).
 At N > 1 it carries "multi_gpu": halo bytes, ghost-element overhead, halo time, host time per step.
 """
 from __future__ import annotations
@@ -51,29 +53,53 @@ def host_threads():
     return max(1, min(16, len(os.sched_getaffinity(0))))
 
 
-def cpu_baseline(n_sample, param_variant):
+def cpu_baseline(conn, xyz, u, p, mesh_name, n_sample, param_variant, gpu_val=None, gpu_rhs=None):
     """Oracle ("port" of the reference loop + MatSetValues-like insertion), timing build (-O3 -march=native, compiled
-    here), on 1 host core and on all of them (rows split over threads: the stand-in for `mpiexec -n P`)."""
+    here) ON THE BENCHMARK MESH ITSELF with all host cores (rows split over threads: the stand-in for `mpiexec -n P`),
+    and on one core on a K(n_sample) sample (config 1 is "1 MPI rank").  With the GPU result of the timed configuration
+    given, also the parity residual of that result against this same-mesh CPU assembly ("same mesh, same
+    fields, same run ... report elem/s, speed-up, and parity residual").  -> (cpu_baseline, parity)"""
     from oracle import oracle as O
     from rdcfes_amd import pihna_params_from_dict, synth
-    conn, xyz = synth.kuhn_tet_mesh(n_sample, order="lex")
-    u = synth.pihna_fields(xyz)
-    p = pihna_params_from_dict(synth.pihna_param_dict(param_variant))
-    pattern = O.build_pattern(4, conn, xyz.shape[0], xyz.shape[0], 5)[:2]
     O.fast_lib()
     nt = host_threads()
     t0 = time.perf_counter()
-    O.assemble(O.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern, threads=nt, fast=True)
-    dt_all = time.perf_counter() - t0
+    pattern = O.build_pattern(4, conn, xyz.shape[0], xyz.shape[0], 5)[:2]
+    t_pat = time.perf_counter() - t0
     t0 = time.perf_counter()
-    O.assemble(O.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern, threads=1, fast=True)
-    dt_1 = time.perf_counter() - t0
-    return {"value": conn.shape[0] / dt_all, "unit": "elements/s", "cores": nt, "kind": "port",
-            "value_1core": conn.shape[0] / dt_1,
-            "sample": f"K({n_sample}) = {conn.shape[0]} TET4 of the same generator/fields/params as the benchmark mesh, full assembly "
-                      f"incl. sorted-row CSR insertion: {dt_all:.1f} s on {nt} cores (rows split over OpenMP threads, elements "
-                      f"straddling two ranges evaluated twice), {dt_1:.1f} s on 1 core (oracle/rdc_oracle.c, gcc -O3 -march=native); "
-                      "stand-in for the reference's libMesh/PETSc path, which cannot be built here"}
+    _, _, val0, rhs0 = O.assemble(O.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern, threads=nt, fast=True)
+    dt_all = time.perf_counter() - t0
+    parity = None
+    if gpu_val is not None:
+        def rel(a, b):   # chunked: no 5 GB temporaries
+            num = den = 0.0
+            for i in range(0, a.size, 1 << 24):
+                d = a[i:i + (1 << 24)] - b[i:i + (1 << 24)]
+                num += float(np.dot(d, d))
+                den += float(np.dot(b[i:i + (1 << 24)], b[i:i + (1 << 24)]))
+            return (num / max(den, 1e-300)) ** 0.5
+        parity = {"rhs_rel_l2": rel(gpu_rhs, rhs0), "matrix_rel_fro": rel(gpu_val, val0), "tolerance": 1e-10,
+                  "against": f"oracle (CPU port) on the benchmark mesh {mesh_name}, same fields and parameters, whole CSR matrix "
+                             f"({val0.size} values) and rhs ({rhs0.size} entries) of the timed configuration's last step"}
+    n_all = conn.shape[0]
+    del val0, rhs0, pattern
+    out = {"value": n_all / dt_all, "unit": "elements/s", "cores": nt, "kind": "port",
+           "sample": f"the benchmark mesh itself, {mesh_name} = {n_all} TET4, same fields / parameters as the GPU run, full assembly incl. "
+                     f"sorted-row CSR insertion: {dt_all:.1f} s on {nt} cores (rows split over OpenMP threads, elements straddling "
+                     f"two ranges evaluated twice; pattern built beforehand in {t_pat:.1f} s, not counted, as for the GPU) "
+                     "(oracle/rdc_oracle.c, gcc -O3 -march=native); stand-in for the reference's libMesh/PETSc path, which "
+                     "cannot be built here"}
+    if n_sample > 0:
+        conn1, xyz1 = synth.kuhn_tet_mesh(n_sample, order="lex")
+        u1 = synth.pihna_fields(xyz1)
+        p1 = pihna_params_from_dict(synth.pihna_param_dict(param_variant))
+        pat1 = O.build_pattern(4, conn1, xyz1.shape[0], xyz1.shape[0], 5)[:2]
+        t0 = time.perf_counter()
+        O.assemble(O.MODEL_PIHNA, 4, conn1, xyz1, 5, p1, u_old=u1, pattern=pat1, threads=1, fast=True)
+        dt_1 = time.perf_counter() - t0
+        out["value_1core"] = conn1.shape[0] / dt_1
+        out["sample_1core"] = f"K({n_sample}) = {conn1.shape[0]} TET4 of the same generator: {dt_1:.1f} s on 1 core"
+    return out, parity
 
 
 def time_config(name, nen, conn, xyz, nvar, setup, call, n_in, solid=False, reps=10, warm=3, note=None):
@@ -103,11 +129,11 @@ def time_config(name, nen, conn, xyz, nvar, setup, call, n_in, solid=False, reps
            "host_prep_s": round(prep_s, 2)}
     if note:
         out["note"] = note
-    # HBM traffic and FP64 rate of this configuration's kernels from the committed counter passes (profiles/pmc_cfg5.json),
+    # HBM traffic and FP64 rate of this configuration's kernels from the committed counter passes (profiles/pmc_configs.json, tools/make_profiles_configs.sh),
     # only when they were taken from the kernel sources built now
     try:
         from rdcfes_amd import build as B
-        t = json.loads((ROOT / "profiles" / "pmc_cfg5.json").read_text())
+        t = json.loads((ROOT / "profiles" / "pmc_configs.json").read_text())
         if t.get("source_hash") == B.source_hash():
             for key, v in t["kernels"].items():
                 if name.startswith(key):
@@ -259,11 +285,18 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged halo, for rehearsing N > 1 on a 1-GPU box")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (rdc_set_option)")
-    ap.add_argument("--cpu-sample", type=int, default=84, help="K(m) sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=60, help="K(m) sample for the 1-core CPU baseline (0 = skip it)")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="N = 1: time the oracle on the benchmark mesh with all host cores and "
+                    "report the parity residual of the GPU result against it (0 = skip)")
     ap.add_argument("--configs", type=int, default=1, help="N = 1: also time the other BASELINE configurations (0 = skip)")
+    ap.add_argument("--configs-only", type=int, default=0, help="1: run ONLY the other BASELINE configurations and print their array (the command "
+                    "tools/make_profiles_configs.sh profiles)")
     ap.add_argument("--handback", type=int, default=1, help="N = 1: also time the CSR hand-back to the host (0 = skip)")
     a = ap.parse_args()
 
+    if a.configs_only:
+        print(json.dumps({"configs": extra_configs()}), flush=True)
+        return
     import torch
     import torch.distributed as dist
     from rdcfes_amd import AssemblyContext, partition, pihna_params_from_dict, synth
@@ -417,16 +450,23 @@ def main():
         if multi:
             out["multi_gpu"] = multi
         if world == 1:
+            gpu_val = gpu_rhs = None
+            if a.cpu_baseline:
+                gpu_val, gpu_rhs = ctx.csr_download()     # the result of the last timed step
             if a.handback:
                 out["handback"] = handback(ctx, lambda: ctx.assemble_pihna(p), n_owned, nnz, n_rows, kern_avg_ms)
+                # end to end when the adapter downloads the CSR every step (never `value`: inputs and outputs of the metric stay in HBM)
+                hb = out["handback"]["kernel_plus_handback_overlapped_ms"] or out["handback"]["kernel_plus_handback_ms"]
+                out["value_with_handback"] = n_elem_global / (hb * 1e-3)
     ctx.close()
     del u_t
     if rank == 0 and world == 1:
         torch.cuda.empty_cache()
+        if a.cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(l_conn, l_xyz, l_u, p, f"K({a.n})", a.cpu_sample, a.params, gpu_val, gpu_rhs)
+            del gpu_val, gpu_rhs
         if a.configs:
             out["configs"] = extra_configs()
-        if a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.params)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -101,16 +101,14 @@ def _compile(src: str, extra=()):
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
     res = _parse_resources(r.stderr) if hip else {}
     # everything that is not a kernel-resource-usage remark (= genuine warnings, with their source excerpts) reaches the log
-    keep, skip = [], 0
+    import re
+    keep, in_diag = [], False
     for ln in r.stderr.splitlines():
-        if "kernel-resource-usage" in ln and "remark:" in ln:
-            skip = 2          # the remark's source excerpt: the quoted line and its caret line
-            continue
-        if skip and ln.lstrip().startswith(("|", "^")) or (skip and "__launch_bounds__" in ln) or (skip and "__global__" in ln):
-            skip -= 1
-            continue
-        skip = 0
-        if ln.strip() and not ln.strip().endswith("remarks generated.") and "warnings generated" not in ln:
+        if re.search(r": (warning|error|fatal error|note):", ln):
+            in_diag = True
+        elif re.search(r": remark:", ln) or re.match(r"\d+ (warnings?|remarks?|errors?)", ln.strip()):
+            in_diag = False
+        if in_diag and ln.strip():
             keep.append(ln)
     if keep:
         sys.stderr.write(f"[rdcfes_amd.build] {src}:\n" + "\n".join(keep) + "\n")

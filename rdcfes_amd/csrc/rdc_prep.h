@@ -128,6 +128,12 @@ struct HostPrepEv {
   int64_t n_visits = 0, n_rows = 0;
   int64_t n_conflicts = 0;           // rows whose node already sits at the same vertex position of their 16-lane group
   int64_t n_group_rows = 0;          // sum over 16-lane groups of the rows they emit (LDS passes per accumulated value)
+  int64_t n_pass_instr = 0;          // sum over waves of the LDS atomic instructions of the row positions they issue (PASS_COST)
+  // LDS atomics of row position i of the PIHNA visit (rdc_tet4_ev.h: 15 symmetric moments to the columns j >= i, 4 of the
+  // non-symmetric one, 5 rhs entries); the coefficient-form kernel (three unknowns) pays the same for every position
+  static constexpr int PASS_COST_PIHNA[4] = {69, 54, 39, 24};
+  static constexpr int PASS_COST_FLAT[4] = {40, 40, 40, 40};
+  static constexpr int COLLISION_COST = 17;   // atomic wave-instructions a colliding row is worth (one extra LDS pass for each of its atomics)
 };
 // needs P.bptr / P.bcol / P.eslot of prep_build; lds_budget = LDS bytes a workgroup may use (3 workgroups per CU: 53 KB)
 // n_interior >= 0: owned nodes [0, n_interior) are "interior" (two-part assembly): clusters do not mix the two kinds

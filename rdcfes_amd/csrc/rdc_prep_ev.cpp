@@ -195,7 +195,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
   E.vslot.assign((size_t)nwg * BLOCK * 4, 0);
   E.ntab.assign((size_t)nwg * MAXN, HostPrepEv::Node{0, 0, 0, 0, 0});
   E.bpart.assign((size_t)nwg * NBP, 0);
-  std::vector<int64_t> rows_w((size_t)nwg, 0), conf_w((size_t)nwg, 0), pass_w((size_t)nwg, 0);
+  std::vector<int64_t> rows_w((size_t)nwg, 0), conf_w((size_t)nwg, 0), pass_w((size_t)nwg, 0), instr_w((size_t)nwg, 0);
   std::vector<size_t> img_w((size_t)nwg, 0);
 #pragma omp parallel for schedule(dynamic, 256)
   for (int64_t w = 0; w < nwg; w++) {
@@ -269,74 +269,181 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       const uint32_t m = conn[(int64_t)v.e * 4 + j];
       return (int)(std::find(cl.begin(), cl.end(), m) - cl.begin());
     };
-    // inside a class of equal r: deal the visits round-robin over their owned nodes, so that the 64 visits a wave gets
-    // spread evenly over the cluster's nodes (a node's elements are neighbours in element order)
-    for (size_t b = 0; b < vv.size();) {
-      size_t e2 = b;
-      while (e2 < vv.size() && vv[e2].r == vv[b].r) e2++;
-      std::vector<std::vector<V>> bucket((size_t)MAXN);
-      std::vector<int> load((size_t)MAXN, 0);
-      for (size_t x = b; x < e2; x++) {      // bucket = the owned node of the visit that has the fewest visits so far
-        int bestn = -1;
-        for (int i = 0; i < vv[x].r; i++) {
-          const int oi = own_index(vv[x], vv[x].own[i]);
-          if (bestn < 0 || load[(size_t)oi] < load[(size_t)bestn]) bestn = oi;
-        }
-        if (bestn < 0) bestn = 0;
-        load[(size_t)bestn]++;
-        bucket[(size_t)bestn].push_back(vv[x]);
-      }
-      size_t out = b;
-      for (size_t round = 0; out < e2; round++)
-        for (int n = 0; n < MAXN; n++)
-          if (round < bucket[(size_t)n].size()) vv[out++] = bucket[(size_t)n][round];
-      b = e2;
-    }
     static const int PERM4[24][4] = {{0,1,2,3},{0,1,3,2},{0,2,1,3},{0,2,3,1},{0,3,1,2},{0,3,2,1},{1,0,2,3},{1,0,3,2},{1,2,0,3},{1,2,3,0},{1,3,0,2},{1,3,2,0},
                                      {2,0,1,3},{2,0,3,1},{2,1,0,3},{2,1,3,0},{2,3,0,1},{2,3,1,0},{3,0,1,2},{3,0,2,1},{3,1,0,2},{3,1,2,0},{3,2,0,1},{3,2,1,0}};
-    const int nperm[5] = {1, 1, 2, 6, 24};
-    // the 2 / 6 permutations of 2 / 3 items are the PERM4 entries that keep the tail fixed
-    auto perm_of = [&](int r2, int q, int* out) {
-      int cnt = 0;
-      for (int x = 0; x < 24; x++) {
-        bool ok = true;
-        for (int y = r2; y < 4; y++) ok = ok && PERM4[x][y] == y;
-        if (!ok) continue;
-        if (cnt == q) { for (int y = 0; y < 4; y++) out[y] = PERM4[x][y]; return; }
-        cnt++;
-      }
-    };
-    // Placement.  An atomic instruction of the kernel costs one LDS pass per 16-lane group that has an active lane, plus
-    // the serialisation of lanes with the same row node (same bank; same ADDRESS for the diagonal block, ~6 cycles per
-    // extra lane).  Visits are taken in descending r (node-interleaved inside a class) and each goes to the group and
-    // vertex order that (1) adds no node twice at a vertex position of the group, (2) does not raise the number of rows
-    // the group emits, (3) fills the fullest such group -- groups end up sorted by r and dense.
-    std::vector<std::array<uint16_t, 4>> used(16);           // [group][vertex position]: owned nodes already there
-    for (auto& u2 : used) u2.fill(0);
-    std::vector<int> fill_g(16, 0), maxr_g(16, 0);
-    for (size_t x = 0; x < vv.size(); x++) {
-      const V& v = vv[x];
-      int oi[4] = {0, 0, 0, 0};
-      for (int i = 0; i < v.r; i++) oi[i] = own_index(v, v.own[i]);
-      int best_g = -1, best_q = 0;
-      long best_cost = 1L << 60;
-      for (int g = 0; g < 16; g++) {
-        if (fill_g[g] >= 16) continue;
-        const long grow = fill_g[g] == 0 ? 4 * v.r : (v.r > maxr_g[g] ? 100 * (v.r - maxr_g[g]) : 0);   // rows the group starts to emit
-        for (int q = 0; q < nperm[v.r]; q++) {
-          int pm[4];
-          perm_of(v.r, q, pm);
-          long cost = grow + (16 - fill_g[g]);
-          for (int i = 0; i < v.r; i++) cost += ((used[(size_t)g][(size_t)i] >> oi[pm[i]]) & 1) ? 1000 : 0;
-          if (cost < best_cost) { best_cost = cost; best_g = g; best_q = q; }
+    // the 1 / 2 / 6 / 24 orders of the r owned vertices = the PERM4 entries that keep the tail fixed
+    static const int NPERM[5] = {1, 1, 2, 6, 24};
+    static const int PERM_R[5][24] = {{0}, {0}, {0, 6}, {0, 2, 6, 8, 12, 14},
+                                      {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23}};
+    // ---- placement -----------------------------------------------------------------------------------------------------
+    // What the kernel pays for.  A wave executes row position i (15 (4 - i) + 9 LDS atomics in the PIHNA kernel: PASS_COST)
+    // when ANY of its lanes has more than i rows, whatever the number of active lanes; and inside a 16-lane group two
+    // lanes with the same row node at the same position hit one bank with every atomic of that position (a COLLISION,
+    // worth ~17 atomic instructions).  The schedule therefore first picks a PROFILE -- how many row positions each of the
+    // four waves issues, e.g. (4, 2, 1, 1) or (4, 2, 1, 0) -- cheapest first among those with enough collision-free lane
+    // slots (a group holds a node once per position: 4 min(16, nown) lanes per wave), then places the visits, deepest
+    // first, each into the shallowest wave that can take it, in the group and with the vertex order that collide with
+    // nothing; a visit that finds no free place ejects one lane that does (one level), and only then accepts a collision.
+    // K(n) meshes: 405 instead of 500 atomic wave-instructions per cluster and no collisions (4.4 before).
+    const int nlanes = (int)vv.size();
+    std::vector<std::array<int, 4>> oiv((size_t)nlanes);
+    for (int x = 0; x < nlanes; x++)
+      for (int i = 0; i < 4; i++) oiv[(size_t)x][(size_t)i] = i < vv[(size_t)x].r ? own_index(vv[(size_t)x], vv[(size_t)x].own[i]) : 0;
+    const int* PASS_COST = P.nvar == 5 ? HostPrepEv::PASS_COST_PIHNA : HostPrepEv::PASS_COST_FLAT;
+    auto prefix_cost = [&](int np) { int c = 0; for (int i = 0; i < np; i++) c += PASS_COST[i]; return c; };
+    // demand[i][a]: lanes that can put node a at position i ONLY IF it is free there, weighted by how few positions they
+    // can use: a lane with k rows spreads 1 / k over the positions 0 .. k - 1 of each of its nodes (scaled by 12)
+    std::array<std::array<int, 16>, 4> demand;
+    for (auto& dm : demand) dm.fill(0);
+    for (int x = 0; x < nlanes; x++) {
+      const int r = vv[(size_t)x].r;
+      for (int i = 0; i < r; i++)
+        for (int p2 = 0; p2 < r; p2++) demand[(size_t)p2][(size_t)oiv[(size_t)x][(size_t)i]] += 12 / r;
+    }
+    struct Placement { std::vector<int8_t> grp, q; long instr = 0, coll = 0; bool ok = false; };
+    auto try_profile = [&](const int (&prof)[4], Placement& out) {
+      std::array<std::array<uint16_t, 4>, 16> used;
+      for (auto& u2 : used) u2.fill(0);
+      int fill_g[16] = {0};
+      std::vector<int8_t>& grp = out.grp; std::vector<int8_t>& qq = out.q;
+      grp.assign((size_t)nlanes, -1); qq.assign((size_t)nlanes, 0);
+      auto conflicts = [&](int g, int x, int q) {
+        const int r = vv[(size_t)x].r; const int* pm = PERM4[PERM_R[r][q]];
+        int c = 0;
+        for (int i = 0; i < r; i++) c += (used[(size_t)g][(size_t)i] >> oiv[(size_t)x][(size_t)pm[i]]) & 1;
+        return c;
+      };
+      auto put = [&](int x, int g, int q) {
+        const int r = vv[(size_t)x].r; const int* pm = PERM4[PERM_R[r][q]];
+        for (int i = 0; i < r; i++) used[(size_t)g][(size_t)i] |= (uint16_t)(1u << oiv[(size_t)x][(size_t)pm[i]]);
+        fill_g[g]++; grp[(size_t)x] = (int8_t)g; qq[(size_t)x] = (int8_t)q;
+      };
+      // NOTE: a collision leaves the node bit set by two lanes; `take` of one of them would clear it for both, so lanes
+      // are only ever taken out of groups in which they do not collide (the repair below moves collision-free lanes only)
+      auto take = [&](int x) {
+        const int g = grp[(size_t)x]; const int r = vv[(size_t)x].r; const int* pm = PERM4[PERM_R[r][(int)qq[(size_t)x]]];
+        for (int i = 0; i < r; i++) used[(size_t)g][(size_t)i] &= (uint16_t)~(1u << oiv[(size_t)x][(size_t)pm[i]]);
+        fill_g[g]--; grp[(size_t)x] = -1;
+      };
+      // best free (group, order) of lane x: shallowest wave first, then the order that keeps the nodes the shallower lanes
+      // will ask for out of the low positions (a lane with k rows can only use positions 0 .. k - 1), then the fullest group
+      auto find_free = [&](int x, int& g_out, int& q_out) {
+        const int r = vv[(size_t)x].r;
+        long best = -1;
+        for (int g = 0; g < 16; g++) {
+          if (prof[g >> 2] < r || fill_g[g] >= 16) continue;
+          for (int q = 0; q < NPERM[r]; q++)
+            if (conflicts(g, x, q) == 0) {
+              const int* pm = PERM4[PERM_R[r][q]];
+              long low = 0;   // demand of the shallower lanes for the (position, node) slots this order takes
+              for (int i = 0; i < r; i++) low += demand[(size_t)i][(size_t)oiv[(size_t)x][(size_t)pm[i]]];
+              const long cost = (long)(prof[g >> 2] - r) * 100000 + low * 20 + (16 - fill_g[g]);
+              if (best < 0 || cost < best) { best = cost; g_out = g; q_out = q; }
+            }
         }
+        return best >= 0;
+      };
+      std::vector<int> pending;
+      for (int x = 0; x < nlanes; x++) {   // vv is sorted by r, descending
+        int g, q;
+        if (find_free(x, g, q)) put(x, g, q); else pending.push_back(x);
       }
-      if (best_g < 0) { wfail = true; break; }
-      conf_w[(size_t)w] += best_cost / 1000;   // rows whose node already sits at the same vertex position of their 16-lane group
-      int pm[4];
-      perm_of(v.r, best_q, pm);
+      out.coll = 0;
+      std::vector<uint8_t> collided((size_t)nlanes, 0);
+      for (int x : pending) {
+        const int r = vv[(size_t)x].r;
+        bool done = false;
+        // eject one collision-free lane y of a group in which x then fits, and find y a free place elsewhere
+        for (int g = 0; g < 16 && !done; g++) {
+          if (prof[g >> 2] < r) continue;
+          for (int y = 0; y < nlanes && !done; y++) {
+            if (grp[(size_t)y] != g || collided[(size_t)y]) continue;
+            const int qy = qq[(size_t)y];
+            take(y);
+            int qx = -1;
+            for (int q = 0; q < NPERM[r]; q++) if (conflicts(g, x, q) == 0) { qx = q; break; }
+            if (qx >= 0) {
+              put(x, g, qx);
+              int g2, q2;
+              if (find_free(y, g2, q2)) { put(y, g2, q2); done = true; }
+              else take(x);
+            }
+            if (!done) put(y, g, qy);
+          }
+        }
+        if (done) continue;
+        // nothing helps: the place with the fewest collisions
+        long best = -1; int bg = -1, bq = 0;
+        for (int g = 0; g < 16; g++) {
+          if (prof[g >> 2] < r || fill_g[g] >= 16) continue;
+          for (int q = 0; q < NPERM[r]; q++) {
+            const long c = conflicts(g, x, q);
+            if (best < 0 || c < best) { best = c; bg = g; bq = q; }
+          }
+        }
+        if (bg < 0) { out.ok = false; return; }
+        put(x, bg, bq);
+        collided[(size_t)x] = 1;
+        for (int y = 0; y < nlanes; y++) if (grp[(size_t)y] == bg && y != x) collided[(size_t)y] = 1;   // conservative: nobody leaves this group any more
+        out.coll += best;
+      }
+      int maxr_w[4] = {0, 0, 0, 0};
+      for (int x = 0; x < nlanes; x++) maxr_w[grp[(size_t)x] >> 2] = std::max(maxr_w[grp[(size_t)x] >> 2], vv[(size_t)x].r);
+      out.instr = 0;
+      for (int wv = 0; wv < 4; wv++) out.instr += prefix_cost(maxr_w[wv]);
+      out.ok = true;
+    };
+    Placement best_pl;
+    {
+      int cnt_ge[5] = {0, 0, 0, 0, 0};   // visits with at least k rows
+      int rmax = 0;
+      for (const V& v : vv) { for (int k = 1; k <= v.r; k++) cnt_ge[k]++; rmax = std::max(rmax, v.r); }
+      struct Cand { int cost; int prof[4]; };
+      std::vector<Cand> cands;
+      const int caps[2] = {4 * std::min(16, (int)cl.size()), 64};
+      for (int pass = 0; pass < 2 && cands.empty(); pass++)
+        for (int a = rmax; a <= rmax; a++)
+          for (int b = 0; b <= a; b++)
+            for (int c2 = 0; c2 <= b; c2++)
+              for (int d2 = 0; d2 <= c2; d2++) {
+                const int prof[4] = {a, b, c2, d2};
+                bool fits = true;
+                for (int k = 1; k <= 4 && fits; k++) {
+                  int slots = 0;
+                  for (int wv = 0; wv < 4; wv++) if (prof[wv] >= k) slots += caps[pass];
+                  fits = cnt_ge[k] <= slots;
+                }
+                if (!fits) continue;
+                Cand cd; cd.cost = 0;
+                for (int wv = 0; wv < 4; wv++) { cd.prof[wv] = prof[wv]; cd.cost += prefix_cost(prof[wv]); }
+                cands.push_back(cd);
+              }
+      std::stable_sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.cost < y.cost; });
+      long best_total = -1;
+      int tried = 0;
+      for (const Cand& cd : cands) {
+        if (best_total >= 0 && cd.cost >= best_total) break;
+        if (tried++ >= 6) break;
+        Placement pl;
+        try_profile(cd.prof, pl);
+        if (!pl.ok) continue;
+        const long total = pl.instr + HostPrepEv::COLLISION_COST * pl.coll;
+        if (best_total < 0 || total < best_total) { best_total = total; best_pl = std::move(pl); }
+        if (best_pl.coll == 0) break;
+      }
+      if (best_total < 0) {   // no profile could take the visits (cannot happen: (rmax, rmax, rmax, rmax) holds 256 lanes)
+        const int prof[4] = {4, 4, 4, 4};
+        try_profile(prof, best_pl);
+      }
+    }
+    if (!best_pl.ok) wfail = true;
+    std::vector<int> fill_g(16, 0), maxr_g(16, 0);
+    for (int x = 0; x < nlanes && !wfail; x++) {
+      const V& v = vv[(size_t)x];
+      const int best_g = best_pl.grp[(size_t)x];
+      const int* pm = PERM4[PERM_R[v.r][(int)best_pl.q[(size_t)x]]];
       int perm[4];
-      for (int i = 0; i < v.r; i++) { perm[i] = v.own[pm[i]]; used[(size_t)best_g][(size_t)i] |= (uint16_t)(1u << oi[pm[i]]); }
+      for (int i = 0; i < v.r; i++) perm[i] = v.own[pm[i]];
       for (int j = v.r; j < 4; j++) perm[j] = v.rest[j - v.r];
       maxr_g[best_g] = std::max(maxr_g[best_g], v.r);
       const size_t lane = (size_t)best_g * 16 + (size_t)fill_g[best_g]++;
@@ -358,6 +465,8 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
         if (li[i] >= cl.size()) wfail = true;
       }
     }
+    conf_w[(size_t)w] = best_pl.coll;
+    instr_w[(size_t)w] = best_pl.instr;
     for (int g = 0; g < 16; g++) pass_w[(size_t)w] += maxr_g[g];
     if (wfail) {
 #pragma omp atomic write
@@ -371,6 +480,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
     E.n_rows += rows_w[(size_t)w];
     E.n_conflicts += conf_w[(size_t)w];
     E.n_group_rows += pass_w[(size_t)w];
+    E.n_pass_instr += instr_w[(size_t)w];
   }
   E.ok = true;
   return std::string();

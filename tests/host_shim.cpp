@@ -505,6 +505,7 @@ int64_t shim_prep_size(int what) {
     case 31: return (int64_t)(g_ev.desc.size() * sizeof(HostPrepEv::Desc));
     case 32: return (int64_t)g_ev.n_group_rows;
     case 33: return (int64_t)g_ev.n_conflicts;
+    case 34: return (int64_t)g_ev.n_pass_instr;
     case 21: return (int64_t)g_gather.gsrc.size();
     case 22: return (int64_t)g_gather.brow.size();
     case 100: return g_prep.n_colours;

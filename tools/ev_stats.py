@@ -44,3 +44,4 @@ print("waves with any visit / cluster:", valid.reshape(nwg,4,64).any(-1).sum(1).
 # group-level (16 lanes) passes
 rg = r.reshape(nwg, 16, 16)
 print("group passes (sum max r per group)/cluster:", rg.max(-1).sum(1).mean(), " rows/cluster:", r.sum((1)).mean())
+print("host statistics: collisions", shim.shim_prep_size(33), " pass instructions / cluster", shim.shim_prep_size(34) / nwg)
