@@ -257,6 +257,54 @@ def handback(ctx, assemble, n_owned, nnz, n_rows, kern_ms, reps=3):
                     "(rdc_csr_values_device_ptr) avoids this copy altogether"}
 
 
+def two_part_host_cost(ctx, p, n_owned, steps=50):
+    """What the two-part step of the N > 1 path costs the HOST at N = 1 (no communication): two C-ABI calls per step
+    (rdc_assemble_pihna_part on the main and on a side stream, the stream joins in between as in the N > 1 step) against
+    the one call of the whole assembly, and the same two parts replayed from a hipGraph (the exchange stays outside it)."""
+    import torch
+    main_s, side_s = torch.cuda.current_stream(), torch.cuda.Stream()
+    ctx.set_option("interior_nodes", int(0.9 * n_owned))   # no ghosts at N = 1: any prefix of the nodes is "interior"
+
+    def two_part():
+        side_s.wait_stream(main_s)
+        ctx.assemble_pihna_part(p, 1, main_s.cuda_stream)
+        ctx.assemble_pihna_part(p, 2, side_s.cuda_stream)
+        main_s.wait_stream(side_s)
+
+    def whole():
+        ctx.assemble_pihna(p)
+
+    def run(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return t_host / steps * 1e6, (time.perf_counter() - t0) / steps * 1e3
+    out = {}
+    out["whole_call_host_us"], out["whole_call_ms_per_step"] = run(whole)
+    out["two_part_host_us"], out["two_part_ms_per_step"] = run(two_part)
+    try:   # both parts on one captured stream: a step is then one hipGraphLaunch
+        g = torch.cuda.CUDAGraph()
+        cap_s = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap_s):
+            ctx.assemble_pihna_part(p, 1, cap_s.cuda_stream)
+            ctx.assemble_pihna_part(p, 2, cap_s.cuda_stream)
+        out["graph_host_us"], out["graph_ms_per_step"] = run(g.replay)
+    except Exception as e:   # capture is best effort: report why it failed rather than hide it
+        out["graph_error"] = str(e)[:200]
+        torch.cuda.synchronize()
+    ctx.set_option("interior_nodes", -1)
+    ctx.set_option("part", 0)
+    out["note"] = ("host time to ENQUEUE one step (no device wait), and wall time per step with the device kept busy; two_part = "
+                   "rdc_assemble_pihna_part x 2 on two streams with the joins of the N > 1 step, no exchange")
+    return out
+
+
 def profile_numbers(n, world):
     """HBM bytes and FP64 flops per launch from the committed rocprofv3 --pmc passes -- only if they were taken from
     the kernel sources that are built now (profiles/pmc_traffic.json carries their hash), else null."""
@@ -291,6 +339,7 @@ def main():
     ap.add_argument("--configs", type=int, default=1, help="N = 1: also time the other BASELINE configurations (0 = skip)")
     ap.add_argument("--configs-only", type=int, default=0, help="1: run ONLY the other BASELINE configurations and print their array (the command "
                     "tools/make_profiles_configs.sh profiles)")
+    ap.add_argument("--two-part", dest="two_part", type=int, default=1, help="N = 1: also measure the host cost of the two-part step of the N > 1 path (0 = skip)")
     ap.add_argument("--handback", type=int, default=1, help="N = 1: also time the CSR hand-back to the host (0 = skip)")
     a = ap.parse_args()
 
@@ -361,14 +410,10 @@ def main():
     def step():
         if overlap:
             halo_s.wait_stream(main_s)      # the previous step has read the ghost rows this exchange overwrites
-            ctx.set_option("part", 1)
-            ctx.assemble_pihna(p)           # interior rows, main stream, concurrent with the exchange
+            ctx.assemble_pihna_part(p, 1, main_s.cuda_stream)   # interior rows, main stream, concurrent with the exchange
             with torch.cuda.stream(halo_s):
                 hx.exchange(u_t)
-            ctx.set_stream(halo_s.cuda_stream)
-            ctx.set_option("part", 2)
-            ctx.assemble_pihna(p)           # rows next to ghosts, behind the exchange on its stream (fills part 1's tail)
-            ctx.set_stream(main_s.cuda_stream)
+            ctx.assemble_pihna_part(p, 2, halo_s.cuda_stream)   # rows next to ghosts, behind the exchange on its stream (fills part 1's tail)
             main_s.wait_stream(halo_s)
             return
         if hx is not None:
@@ -453,6 +498,8 @@ def main():
             gpu_val = gpu_rhs = None
             if a.cpu_baseline:
                 gpu_val, gpu_rhs = ctx.csr_download()     # the result of the last timed step
+            if a.two_part:
+                out["two_part_host"] = two_part_host_cost(ctx, p, n_owned)
             if a.handback:
                 out["handback"] = handback(ctx, lambda: ctx.assemble_pihna(p), n_owned, nnz, n_rows, kern_avg_ms)
                 # end to end when the adapter downloads the CSR every step (never `value`: inputs and outputs of the metric stay in HBM)

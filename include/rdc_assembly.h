@@ -261,6 +261,13 @@ int rdc_assemble_adpm(rdc_ctx* ctx, const rdc_adpm_params* p);
 int rdc_assemble_proteas(rdc_ctx* ctx, const rdc_proteas_params* p);
 /* residual (+ Jacobian if request_jacobian) of the SolidSystem; nvar must be 3 */
 int rdc_solid_assemble(rdc_ctx* ctx, const rdc_solid_params* p, int request_jacobian);
+/* One part of a two-part step in ONE call: as the assemble call of the same name with "part" = part (0 = whole, 1, 2) and
+ * on `hip_stream` (a hipStream_t; NULL = the default stream) for this call only -- the context's "part" option and stream
+ * are left as they were.  The step of a partitioned run (src/pihna.C:801 system.update() overlapped with the assembly of
+ * the interior rows) is then: rdc_assemble_pihna_part(ctx, p, 1, main); [halo exchange on side]; rdc_assemble_pihna_part(ctx, p, 2, side). */
+int rdc_assemble_pihna_part(rdc_ctx* ctx, const rdc_pihna_params* p, int part, void* hip_stream);
+int rdc_assemble_hcc_part(rdc_ctx* ctx, const rdc_hcc_params* p, int part, void* hip_stream);
+int rdc_solid_assemble_part(rdc_ctx* ctx, const rdc_solid_params* p, int request_jacobian, int part, void* hip_stream);
 
 /* ---- results ---- */
 int rdc_csr_values_device_ptr(rdc_ctx* ctx, double** d_val, double** d_rhs);

@@ -44,6 +44,9 @@ SIGNATURES = {
     "rdc_assemble_ripf": (C.c_int, [ctx_p, P(RipfParams)]),
     "rdc_assemble_hcc": (C.c_int, [ctx_p, P(HccParams)]),
     "rdc_solid_assemble": (C.c_int, [ctx_p, P(SolidParams), C.c_int]),
+    "rdc_assemble_pihna_part": (C.c_int, [ctx_p, P(PihnaParams), C.c_int, C.c_void_p]),
+    "rdc_assemble_hcc_part": (C.c_int, [ctx_p, P(HccParams), C.c_int, C.c_void_p]),
+    "rdc_solid_assemble_part": (C.c_int, [ctx_p, P(SolidParams), C.c_int, C.c_int, C.c_void_p]),
     "rdc_csr_values_device_ptr": (C.c_int, [ctx_p, P(C.c_void_p), P(C.c_void_p)]),
     "rdc_csr_download": (C.c_int, [ctx_p, P(dbl), P(dbl)]),
     "rdc_csr_download_rows": (C.c_int, [ctx_p, i64, i64, C.c_void_p, C.c_void_p, C.c_int]),

@@ -36,6 +36,7 @@ class AssemblyContext:
         if rc != 0:
             raise RdcError(rc, self._lib.rdc_last_error(None).decode())
         self._h = h
+        self.device = int(device)
         self.n_elem = self.n_node = self.n_owned = 0
         self.nvar = 0
 
@@ -99,6 +100,24 @@ class AssemblyContext:
         if xyz.shape != (self.n_node, 3):
             raise ValueError("xyz shape mismatch")
         self._ck(self._lib.rdc_mesh_update_coords(self._h, _dp(xyz)))
+
+    def coords_device_ptr(self):
+        """device address of the CURRENT node coordinates [n_node][3] (rdc_mesh_coords_device_ptr)"""
+        p = C.c_void_p()
+        self._ck(self._lib.rdc_mesh_coords_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def coords_tensor(self):
+        """zero-copy torch view [n_node][3] of the context's current coordinates: the moving-mesh models update them in
+        place on the device (mesh = solution of the solid system) and the halo exchange writes their ghost rows"""
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (self.n_node, 3), "typestr": "<f8", "data": (self.coords_device_ptr(), False),
+                                      "version": 2, "strides": None}
+        return torch.as_tensor(v, device=torch.device("cuda", self.device))
 
     def n_colours(self):
         nc = C.c_int()
@@ -215,6 +234,16 @@ class AssemblyContext:
     def assemble_adpm(self, p):
         """assemble_adpm (src/adpm.C:324-652); the tract vectors go into FIELD_ELEM_TRACTS first."""
         self._ck(self._lib.rdc_assemble_adpm(self._h, C.byref(p)))
+
+    def assemble_pihna_part(self, p: PihnaParams, part, stream=0):
+        """one part (1 | 2, 0 = whole) of a two-part step on the given hipStream_t, in one C-ABI call"""
+        self._ck(self._lib.rdc_assemble_pihna_part(self._h, C.byref(p), int(part), C.c_void_p(int(stream) or None)))
+
+    def assemble_hcc_part(self, p: HccParams, part, stream=0):
+        self._ck(self._lib.rdc_assemble_hcc_part(self._h, C.byref(p), int(part), C.c_void_p(int(stream) or None)))
+
+    def solid_assemble_part(self, p: SolidParams, request_jacobian, part, stream=0):
+        self._ck(self._lib.rdc_solid_assemble_part(self._h, C.byref(p), 1 if request_jacobian else 0, int(part), C.c_void_p(int(stream) or None)))
 
     def solid_assemble(self, p: SolidParams, request_jacobian=True):
         self._ck(self._lib.rdc_solid_assemble(self._h, C.byref(p), 1 if request_jacobian else 0))

@@ -55,6 +55,10 @@ struct rdc_ctx {
   bool ev_tried = false;           // the element-visit lists of this mesh have been built (or found impossible)
   int64_t ev_perm_interior = -2;   // "interior_nodes" value the uploaded workgroup order was built for
   int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
+  int scl_interior = -1, scl_n_wg_interior = 0;   // "interior_nodes" the cluster lists were built with; leading interior clusters
+  int64_t scl_part1_nodes = 0;
+  hipEvent_t solid_part1_event = nullptr;   // recorded behind part 1 of a two-part solid assembly (the sides of part 2 wait for it)
+  bool solid_part1_pending = false;
   int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
   int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
@@ -318,7 +322,7 @@ int build_ev_lists(rdc_ctx* c, const uint32_t* conn) {
 int ensure_cluster_lists(rdc_ctx* c, int order_of_caller) {
   int rc;
   const int want_order = c->opt_solid_cl_order < 0 ? (c->solid_cl_state == 1 ? c->solid_cl_order : order_of_caller) : c->opt_solid_cl_order;
-  if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != want_order)) c->solid_cl_state = 0;
+  if (c->solid_cl_state != 0 && (c->solid_cl_waves != c->opt_solid_cl_waves || c->solid_cl_order != want_order || c->scl_interior != c->opt_interior)) c->solid_cl_state = 0;
   if (c->solid_cl_state != 0) return RDC_OK;
   const int cw = c->opt_solid_cl_waves / 10, pw = c->opt_solid_cl_waves % 10;
   HostPrepCl::Limits lim;
@@ -334,7 +338,8 @@ int ensure_cluster_lists(rdc_ctx* c, int order_of_caller) {
   std::vector<uint32_t> conn_h((size_t)c->prep.n_elem * 8);      // the context keeps the connectivity on the device only
   RDC_HIP(c, hipMemcpyAsync(conn_h.data(), c->conn.p, conn_h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   RDC_HIP(c, hipStreamSynchronize(c->stream));
-  const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl);
+  const std::string err = prep_build_cl(c->prep, conn_h.data(), lim, cl, c->opt_interior);
+  c->scl_interior = c->opt_interior;
   c->solid_cl_waves = c->opt_solid_cl_waves;
   c->solid_cl_order = want_order;
   if (!err.empty()) {
@@ -350,18 +355,25 @@ int ensure_cluster_lists(rdc_ctx* c, int order_of_caller) {
   RDC_HIP(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
   c->scl_max_row_doubles = cl.max_row_doubles;
   c->scl_n_wg = (int)cl.desc.size();
+  c->scl_n_wg_interior = (int)cl.n_wg_interior;
+  c->scl_part1_nodes = cl.part1_nodes;
   c->solid_cl_state = 1;
   return RDC_OK;
 }
 
-ClDev cluster_view(const rdc_ctx* c) {
+// part 0: every cluster; 1: the leading clusters of interior nodes; 2: the rest (the kernels index the lists by blockIdx.x)
+ClDev cluster_view(const rdc_ctx* c, int part = 0) {
   ClDev v;
-  v.n_wg = c->scl_n_wg; v.cw = c->solid_cl_waves / 10; v.pw = c->solid_cl_waves % 10;
-  v.desc = (const HostPrepCl::Desc*)c->scl_desc.p;
-  v.ntab = (const HostPrepCl::Node*)c->scl_ntab.p;
-  v.eid = (const uint32_t*)c->scl_eid.p;
-  v.pair = (const uint32_t*)c->scl_pair.p;
-  v.pslot = (const uint32_t*)c->scl_pslot.p;
+  v.cw = c->solid_cl_waves / 10; v.pw = c->solid_cl_waves % 10;
+  const int split = c->scl_interior >= 0 ? c->scl_n_wg_interior : 0;
+  const size_t b = part == 2 ? (size_t)split : 0;
+  v.n_wg = part == 1 ? split : (part == 2 ? c->scl_n_wg - split : c->scl_n_wg);
+  const size_t max_nodes = (size_t)v.cw * 8, max_pairs = (size_t)v.cw * 64, max_elems = (size_t)v.pw * 64, wpp = (size_t)c->prep.nen / 4;
+  v.desc = (const HostPrepCl::Desc*)c->scl_desc.p + b;
+  v.ntab = (const HostPrepCl::Node*)c->scl_ntab.p + b * max_nodes;
+  v.eid = (const uint32_t*)c->scl_eid.p + b * max_elems;
+  v.pair = (const uint32_t*)c->scl_pair.p + b * max_pairs;
+  v.pslot = (const uint32_t*)c->scl_pslot.p + b * max_pairs * wpp;
   v.max_row_doubles = c->scl_max_row_doubles;
   return v;
 }
@@ -462,6 +474,14 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     a.ev.nls = c->prep_ev.nls;
     a.ev.max_out_doubles = c->prep_ev.max_out_doubles;
   }
+  // HEX8, three (five) unknowns: producer / consumer cluster kernel; a two-part call launches the interior clusters / the rest
+  // (the persistent form, "hex_kernel" = 2, assembles whole meshes only)
+  bool hex_cl = false;
+  if (a.nen == 8 && (M::NV == 3 || M::NV == 5) && c->opt_hex_kernel != 1 && (c->opt_part == 0 || c->opt_hex_kernel == 0) &&
+      a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
+    if ((rc = ensure_cluster_lists(c, 0))) return rc;
+    hex_cl = c->solid_cl_state == 1;
+  }
   bool pattern_ok = evc_model;
   if constexpr (std::is_same<M, Pihna>::value) pattern_ok = pihna_pattern_applies(p);
   const bool ev_path = a.use_ev && (std::is_same<M, Pihna>::value || evc_model) && a.nen == 4 && a.variant != RDC_VARIANT_GENERIC &&
@@ -486,6 +506,16 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
       if (c->part1_packed) { a.pack_part = 2; a.pack_event = c->pack_event; }
       c->part1_packed = false;
     }
+  } else
+  if (c->opt_part != 0 && hex_cl) {
+    // HEX8 cluster kernels: the cluster lists respect "interior_nodes" (interior clusters first)
+    c->part1_packed = false;
+    if (c->opt_part == 1) {
+      c->part1_nodes = c->scl_interior >= 0 ? c->scl_part1_nodes : 0;
+      if (c->scl_interior < 0 || c->scl_n_wg_interior == 0) { c->part1_nodes = 0; return RDC_OK; }
+    }
+    a.cl = cluster_view(c, c->scl_interior >= 0 ? c->opt_part : (c->opt_part == 2 ? 0 : 1));
+    if (a.cl.n_wg == 0) return RDC_OK;
   } else
   if (c->opt_part != 0) {
     // two-part assembly (halo overlap): part 1 = the leading workgroups whose nodes are all interior, part 2 = the
@@ -514,13 +544,9 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   } else {
     c->part1_packed = false;
   }
-  // HEX8, three unknowns: producer / consumer cluster kernel (whole-mesh assembly only; a two-part call uses the pair kernels)
-  if (a.nen == 8 && (M::NV == 3 || M::NV == 5) && c->opt_hex_kernel != 1 && c->opt_part == 0 && a.strategy == RDC_SCATTER_ROWGATHER && c->opt_solid_cl_waves == 31) {
-    if ((rc = ensure_cluster_lists(c, 0))) return rc;
-    if (c->solid_cl_state == 1) {
-      a.cl = cluster_view(c);
-      a.cl.grid = c->opt_hex_kernel == 2 ? 2 * c->n_cu : 0;   // persistent form: the workgroups resident at once
-    }
+  if (hex_cl && c->opt_part == 0) {
+    a.cl = cluster_view(c);
+    a.cl.grid = c->opt_hex_kernel == 2 ? 2 * c->n_cu : 0;   // persistent form: the workgroups resident at once
   }
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
@@ -540,6 +566,21 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   return RDC_OK;
 }
 
+// one call per part of a two-part step: "part" and the stream for this call only (a step of the multi-GPU harness is then
+// two C-ABI calls instead of six: set_option, assemble, set_stream, set_option, assemble, set_stream)
+template <class F>
+int with_part(rdc_ctx* c, int part, void* stream, F&& call) {
+  if (!c) return RDC_ERR_INVALID;
+  if (part < 0 || part > 2) return fail(c, RDC_ERR_INVALID, "part must be 0, 1 or 2");
+  const int part0 = c->opt_part;
+  const hipStream_t s0 = c->stream;
+  c->opt_part = part;
+  c->stream = (hipStream_t)stream;
+  const int rc = call();
+  c->opt_part = part0;
+  c->stream = s0;
+  return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -597,6 +638,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->pack_event) (void)hipEventDestroy(c->pack_event);
+  if (c->solid_part1_event) (void)hipEventDestroy(c->solid_part1_event);
   delete c;
   return RDC_OK;
 }
@@ -924,6 +966,16 @@ int rdc_assemble_hcc(rdc_ctx* c, const rdc_hcc_params* p) { return assemble_rd<H
 int rdc_assemble_adpm(rdc_ctx* c, const rdc_adpm_params* p) { return assemble_rd<Adpm>(c, p, 3, false); }
 int rdc_assemble_proteas(rdc_ctx* c, const rdc_proteas_params* p) { return assemble_rd<Proteas>(c, p, 5, true); }
 
+int rdc_assemble_pihna_part(rdc_ctx* c, const rdc_pihna_params* p, int part, void* stream) {
+  return with_part(c, part, stream, [&] { return assemble_rd<Pihna>(c, p, 5, false); });
+}
+int rdc_assemble_hcc_part(rdc_ctx* c, const rdc_hcc_params* p, int part, void* stream) {
+  return with_part(c, part, stream, [&] { return assemble_rd<Hcc>(c, p, 3, false); });
+}
+int rdc_solid_assemble_part(rdc_ctx* c, const rdc_solid_params* p, int request_jacobian, int part, void* stream) {
+  return with_part(c, part, stream, [&] { return rdc_solid_assemble(c, p, request_jacobian); });
+}
+
 int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobian) {
   if (!c) return RDC_ERR_INVALID;
   if (!p) return fail(c, RDC_ERR_INVALID, "null parameter struct");
@@ -947,9 +999,6 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
   a.side_disp = (const double*)c->side_disp.p;
   a.params = *p;
   a.request_jacobian = request_jacobian;
-  // two-part assembly (halo overlap) is a feature of the reaction-diffusion row-gather kernel: the solid system
-  // assembles everything in part 2
-  if (c->opt_part == 1) return RDC_OK;
   a.val = (double*)c->val.p;
   a.rhs = (double*)c->rhs.p;
   a.stream = c->stream;
@@ -966,10 +1015,26 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
     if (c->solid_cl_state != 1 && c->opt_solid_kernel == 3) return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: %s", c->err);
     if (c->solid_cl_state == 1) {
       kernel = 3;
-      a.cl = cluster_view(c);
+      a.cl = cluster_view(c, c->scl_interior >= 0 ? c->opt_part : (c->opt_part == 1 ? 1 : 0));
     }
   } else if (c->opt_solid_kernel == 3) {
     return fail(c, RDC_ERR_UNSUPPORTED, "fused solid kernel: HEX8 tangent requests only");
+  }
+  // two-part assembly (halo overlap): the fused cluster kernel launches the clusters of interior nodes in part 1 and the rest
+  // (+ the penalty sides, which add into rows of both kinds) in part 2; the two-pass and coloured forms assemble everything in part 2
+  if (c->opt_part == 1) {
+    c->part1_nodes = 0;
+    if (kernel != 3 || c->scl_interior < 0 || a.cl.n_wg == 0) return RDC_OK;
+    c->part1_nodes = c->scl_part1_nodes;
+    a.n_sides = 0;
+    if (!c->solid_part1_event) RDC_HIP(c, hipEventCreateWithFlags(&c->solid_part1_event, hipEventDisableTiming));
+    a.done_record = c->solid_part1_event;
+    c->solid_part1_pending = true;
+  } else if (c->opt_part == 2 && c->solid_part1_pending) {
+    a.sides_wait = c->solid_part1_event;
+    c->solid_part1_pending = false;
+  } else {
+    c->solid_part1_pending = false;
   }
   a.kernel = kernel;
   if (a.kernel == 0) {

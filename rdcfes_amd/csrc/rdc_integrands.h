@@ -54,11 +54,10 @@ struct Coef {
 // 1/x.  The reference divides (IEEE); on the device a correctly rounded FP64 division costs ~11
 // instructions, so quotients sharing a denominator use one reciprocal: v_rcp_f64 (~1e-8 rel) plus
 // two Newton steps (<= 1 ulp off the IEEE quotient, far inside the 1e-10 parity bound).
-// NaN and +-inf arguments propagate as in the quotient they replace.  x == 0 does NOT: the IEEE quotient is +-inf,
-// here v_rcp gives +-inf and the first Newton step fma(-0, inf, 1) turns it into NaN (the host build, 1.0 / x,
-// returns inf).  The callers cannot see the difference on admissible states: PIHNA's Ve_ = v * rcp(c + h + v) is
-// NaN for c + h + v == 0 either way when v == 0 (0 * inf), and c + h + v == 0 with v > 0 needs a negative c or h,
-// which check_solution has clamped away (src/pihna.C:785-790); det == 0 is rejected by libMesh before assembly.
+// The special cases are those of the IEEE quotient 1.0 / x: the Newton steps alone turn x == +-0 (v_rcp: +-inf,
+// fma(-0, inf, 1) = NaN) and x == +-inf into NaN, so the result passes through v_div_fixup_f64 (one instruction), which
+// returns +-inf, +-0 and NaN exactly where the division does -- PIHNA's Ve_ = v / (c + h + v) with c + h + v == 0 and
+// v > 0 is +inf as upstream (src/pihna.C:477-498 then takes the Ve_ >= 1 branch), not NaN.
 RDC_HD double rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
@@ -66,7 +65,7 @@ RDC_HD double rcp(double x) {
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-x, r, 1.0);
   r = __builtin_fma(r, e, r);
-  return r;
+  return __builtin_amdgcn_div_fixup(r, x, 1.0);
 #else
   return 1.0 / x;
 #endif

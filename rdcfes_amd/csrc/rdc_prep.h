@@ -168,10 +168,14 @@ struct HostPrepCl {
   std::vector<uint32_t> pair;        // [n_wg][max_pairs] local element | local row node << 8 | owned-node index << 16; ~0u = none (order: rdc_prep_cl.cpp)
   std::vector<uint32_t> pslot;       // [n_wg][max_pairs][nen / 4]: byte j = column slot of local node j in the pair's row
   size_t max_row_doubles = 0;
+  int64_t n_wg_interior = 0;         // leading clusters whose nodes are all interior (two-part assembly)
+  int64_t part1_nodes = 0;           // the rows of nodes [0, part1_nodes) are complete after those clusters
   // statistics
   int64_t n_elem_visits = 0, n_pairs = 0;
 };
-std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPrepCl::Limits& lim, HostPrepCl& out);
+// n_interior >= 0: owned nodes [0, n_interior) are "interior" (two-part assembly): clusters do not mix the two kinds and the
+// interior clusters come first in the lists ([0, n_wg_interior))
+std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPrepCl::Limits& lim, HostPrepCl& out, int64_t n_interior = -1);
 
 // returns empty string on success, else an error message
 std::string prep_build(int nen, int64_t n_elem, int64_t n_node, int64_t n_owned, const uint32_t* conn,

@@ -25,7 +25,7 @@
 
 namespace rdc {
 
-std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPrepCl::Limits& lim, HostPrepCl& C) {
+std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPrepCl::Limits& lim, HostPrepCl& C, int64_t n_interior) {
   C = HostPrepCl();
   C.lim = lim;
   C.nvar = P.nvar;
@@ -112,7 +112,8 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
           nel++;
           for (int j = 0; j < nen; j++) {
             const uint32_t m = conn[(int64_t)e * nen + j];
-            if ((int64_t)m < n_owned && cluster_of[m] == -1) {
+            // two-part assembly: a cluster never mixes interior nodes (rows assembled before the halo exchange has landed) with the others
+            if ((int64_t)m < n_owned && cluster_of[m] == -1 && (n_interior < 0 || (((int64_t)m < n_interior) == (seed < n_interior)))) {
               if (gstamp[m] != stamp) { gstamp[m] = stamp; gain[m] = 0; cand.push_back(m); }
               gain[m]++;
             }
@@ -142,6 +143,21 @@ std::string prep_build_cl(const HostPrep& P, const uint32_t* conn, const HostPre
       for (uint32_t c : rejected) cluster_of[c] = -1;
       clusters.push_back(std::move(cl));
     }
+  }
+  // two-part assembly: the clusters of interior nodes first (the kernels launch a leading / trailing sub-range of the lists);
+  // cluster_of follows the new numbering
+  if (n_interior >= 0) {
+    std::stable_partition(clusters.begin(), clusters.end(), [&](const std::vector<uint32_t>& cl) { return (int64_t)cl[0] < n_interior; });
+    int64_t bound = n_interior;
+    for (size_t w = 0; w < clusters.size(); w++) {
+      const bool interior = (int64_t)clusters[w][0] < n_interior;
+      if (interior) C.n_wg_interior = (int64_t)w + 1;
+      for (uint32_t n : clusters[w]) {
+        cluster_of[n] = (int32_t)w;
+        if (!interior) bound = std::min<int64_t>(bound, (int64_t)n);
+      }
+    }
+    C.part1_nodes = bound;   // rows [0, bound) are complete once the interior clusters have run
   }
   const int64_t nwg = (int64_t)clusters.size();
   // ---- per-workgroup lists ------------------------------------------------------------------------------------------

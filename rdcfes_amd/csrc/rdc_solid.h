@@ -33,6 +33,8 @@ struct SolidArgs {
   int split;                   // pass 1: 1 = one thread per element row (default), 0 = columns of a HEX8 row split between two threads
   int store_mode;              // pass 1 diagnostics: 0 = staged stores (default), 1 = direct per-thread stores, 2 = none (timing only)
   int gather;                  // pass 2: 0 = stores staged through LDS (runs of consecutive doubles), 1 = 24-byte pieces
+  hipEvent_t sides_wait = nullptr;    // two-part assembly, part 2: the sides add into rows part 1 wrote on another stream: wait for it first
+  hipEvent_t done_record = nullptr;   // two-part assembly, part 1: recorded behind the element kernel
 };
 hipError_t launch_solid(const SolidArgs& a);
 hipError_t launch_solid_cl(const SolidArgs& a);   // element part only (rdc_solid_cl.hip); launch_solid adds the sides

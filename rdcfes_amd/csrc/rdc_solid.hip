@@ -781,8 +781,10 @@ hipError_t launch_solid_post(const SolidArgs& a, double* out) {
 
 hipError_t launch_solid(const SolidArgs& a) {
   if (a.kernel == 3) {
-    const hipError_t e = launch_solid_cl(a);
-    if (e != hipSuccess) return e;
+    if (a.cl.n_wg > 0) {   // a part of a two-part assembly may hold no cluster
+      const hipError_t e = launch_solid_cl(a);
+      if (e != hipSuccess) return e;
+    }
   } else if (a.kernel == 0) {
     if (a.nen == 4) launch_two_pass<4>(a); else launch_two_pass<8>(a);
   } else
@@ -800,7 +802,9 @@ hipError_t launch_solid(const SolidArgs& a) {
                          a.elem_material, a.materials, a.params.pseudo_time, a.params.use_symmetry, a.request_jacobian,
                          a.val, a.rhs);
   }
+  if (a.done_record) (void)hipEventRecord(a.done_record, a.stream);
   if (a.n_sides > 0) {
+    if (a.sides_wait) (void)hipStreamWaitEvent(a.stream, a.sides_wait, 0);
     const int block = 64;
     const unsigned grid = (unsigned)((a.n_sides + block - 1) / block);
     if (a.nen == 4)

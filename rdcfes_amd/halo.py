@@ -50,6 +50,42 @@ class HaloExchange:
         self.recv_view = views(rb, lp.recv_ids, self.recv_peers)
         self._ops = None   # the P2POp list is the same every step: built once (needs the process group to exist)
 
+    def exchange_many(self, fields):
+        """Several nodal fields in ONE grouped message per peer: fields = [tensor [n_node_local][w_k], ...] with
+        sum(w_k) == nvar.  The coupled HCC + solid step (BASELINE config 5) moves the HCC unknowns (3 per node) and the
+        CURRENT coordinates of the moving mesh (3 per node: the solid system's solution, src/solid_system.C:103-123)
+        together: the message count, not the bytes, is what a step pays for."""
+        if sum(int(f.shape[1]) for f in fields) != self.nvar:
+            raise ValueError("field widths do not add up to the exchange's nvar")
+        if not self.send_peers and not self.recv_peers:
+            return
+        if self.send_idx.numel():
+            o = 0
+            for f in fields:
+                w = int(f.shape[1])
+                self.send_buf[:, o:o + w].copy_(f.index_select(0, self.send_idx))
+                o += w
+        self._round()
+        if self.recv_idx.numel():
+            o = 0
+            for f in fields:
+                w = int(f.shape[1])
+                f.index_copy_(0, self.recv_idx, self.recv_buf[:, o:o + w])
+                o += w
+
+    def _round(self):
+        """send_buf -> peers -> recv_buf (one grouped isend / irecv round)"""
+        if self.send_idx.numel() and self.host_staged:
+            self.send_host.copy_(self.send_buf, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        if self._ops is None:
+            self._ops = [dist.P2POp(dist.irecv, self.recv_view[q], q, group=self.group) for q in self.recv_peers]
+            self._ops += [dist.P2POp(dist.isend, self.send_view[q], q, group=self.group) for q in self.send_peers]
+        for w in dist.batch_isend_irecv(self._ops):
+            w.wait()
+        if self.recv_idx.numel() and self.host_staged:
+            self.recv_buf.copy_(self.recv_host, non_blocking=True)
+
     def exchange(self, u: torch.Tensor):
         """u: [n_node_local][nvar]; owned rows are read, ghost rows are overwritten in place."""
         if not self.send_peers and not self.recv_peers:

@@ -42,7 +42,7 @@ def test_python_binding_table_matches_header(lib_path):
 
 def test_abi_version_and_struct_sizes(lib_path):
     from rdcfes_amd import _lib, HccParams, PihnaParams, RipfParams, SolidMaterial, SolidParams
-    assert _lib.load().rdc_abi_version() == 1
+    assert _lib.load().rdc_abi_version() == _lib.header_abi_version() == 3
     # POD layouts: all doubles (+ one padded int pair)
     assert C.sizeof(PihnaParams) == 23 * 8
     assert C.sizeof(RipfParams) == 28 * 8 + 8

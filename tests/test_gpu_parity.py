@@ -677,3 +677,31 @@ def test_chunked_handback_follows_the_part1_bound(params, opts):
     assert rel(val, val0) < 1e-13 and rel(rhs, rhs0) < 1e-13
     if not opts and params == "shipped":
         assert n1 > 0.3 * n_int                             # the default path does split
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("moments", [1, 0])
+def test_pihna_zero_cell_sum_with_positive_vasculature(oracle, moments):
+    """c + h + v == 0 with v > 0 at the quadrature points (c = -v on a slab of nodes; not reachable after check_solution's
+    clamp, but the IEEE quotient is defined): upstream's Ve_ = v / (c + h + v) is +inf and takes the Ve_ >= 1 branch
+    (src/pihna.C:477-498); the device reciprocal must do the same (rcp(): v_div_fixup after the Newton steps), not NaN."""
+    conn, xyz = synth.kuhn_tet_mesh(8, order="random")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    slab = (xyz[:, 0] > 0.3) & (xyz[:, 0] < 0.8)
+    u[slab, 3] = 7170.0
+    u[slab, 1] = -7170.0
+    u[slab, 2] = 0.0
+    inside = slab[conn].all(axis=1)
+    assert inside.sum() > 100                                   # elements whose every point has c + h + v == 0 exactly
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("moments", moments)
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val, rhs = ctx.csr_download()
+    assert np.array_equal(np.isnan(val), np.isnan(val0)) and np.array_equal(np.isnan(rhs), np.isnan(rhs0))
+    ok, okr = ~np.isnan(val0), ~np.isnan(rhs0)
+    assert ok.mean() > 0.5
+    assert rel(val[ok], val0[ok]) < TOL and rel(rhs[okr], rhs0[okr]) < TOL

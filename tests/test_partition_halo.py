@@ -151,3 +151,52 @@ def test_eight_way_partition_of_k20_plan_and_exchange():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert len(res) == 8 and all(ok for _, ok, _ in res)
+
+
+def _coord_halo_worker(rank, world, port, q):
+    """cfg5 halo plan on a HEX8 partition: the HCC unknowns (3 per node) and the current coordinates of the moving mesh
+    (3 per node) travel in ONE grouped message per peer (HaloExchange.exchange_many)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        conn, Xu = synth.hex_mesh(7, jitter=0.1, order="random")
+        part = partition.partition_rcb(Xu[conn].mean(axis=1), world)
+        lp = partition.build_local(conn, Xu, part, rank, world)
+        x_true = Xu + synth.solid_displacement(Xu)          # the moved mesh
+        u_true = synth.hcc_fields(Xu)
+        u = torch.full((lp.node_global.size, 3), float("nan"), dtype=torch.float64)
+        x = torch.full((lp.node_global.size, 3), float("nan"), dtype=torch.float64)
+        u[:lp.n_owned] = torch.from_numpy(u_true[lp.node_global[:lp.n_owned]])
+        x[:lp.n_owned] = torch.from_numpy(x_true[lp.node_global[:lp.n_owned]])
+        hx = HaloExchange(lp, 6, "cpu")
+        ok = True
+        for step in range(2):
+            hx.exchange_many([u, x])
+            ok = ok and bool(torch.equal(u, torch.from_numpy(u_true[lp.node_global]))) and bool(torch.equal(x, torch.from_numpy(x_true[lp.node_global])))
+            u[:lp.n_owned] *= 0.5; u_true = u_true * 0.5           # next step's state; the ghost rows are stale until the exchange
+            x[:lp.n_owned] += 0.01; x_true = x_true + 0.01
+        # the interior-first numbering holds for hexes too: no element of an interior node contains a ghost
+        touches_ghost = (lp.conn >= lp.n_owned).any(axis=1)
+        near = np.unique(lp.conn[touches_ghost])
+        ok = ok and not np.any(near[near < lp.n_owned] < lp.n_interior) and lp.n_interior > 0
+        dist.barrier()
+        q.put((rank, ok, hx.bytes_per_step, len(hx._ops)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_coordinate_halo_plan_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_coord_halo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    assert all(nops == 2 for _, _, _, nops in res)          # one send + one receive per peer: both fields in one message
+    assert all(b % 48 == 0 and b > 0 for _, _, b, _ in res)  # 6 doubles per interface node

@@ -6,7 +6,7 @@ tag=${1:-r01}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="bench.py --steps 10 --warmup 3 --cpu-baseline 0 --configs 0 --handback 0"
+ARGS="bench.py --steps 10 --warmup 3 --cpu-baseline 0 --configs 0 --handback 0 --two-part 0"
 # 1. kernel trace + stats of the bench command itself (no counters in this run)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $ARGS > $out/bench_under_rocprof.json 2> $out/stats.err
 # 2. counters, each set in its own run (no trace domains besides kernel-trace)
@@ -20,6 +20,6 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc$i -- python3 $ARGS > $out/pmc$i.json 2> $out/pmc$i.err || { echo "FAILED: pmc pass $i ($ctrs)"; tail -5 $out/pmc$i.err; exit 1; }
 done
 # 3. plain bench run (un-profiled) for the headline line
-python3 bench.py --cpu-baseline 0 --configs 0 --handback 0 > $out/bench.json 2> $out/bench.err
+python3 bench.py --cpu-baseline 0 --configs 0 --handback 0 --two-part 0 > $out/bench.json 2> $out/bench.err
 python3 tools/profile_report.py $out > $out/REPORT.md
 cat $out/REPORT.md

@@ -3,7 +3,7 @@
 import csv, glob, json, sys, collections
 d = sys.argv[1]
 print(f"# rocprofv3 evidence ({d})\n")
-print("Command profiled: `python3 bench.py --steps 10 --warmup 3 --cpu-baseline 0 --configs 0 --handback 0` (PIHNA, K(119), 1 GPU).\n")
+print("Command profiled: `python3 bench.py --steps 10 --warmup 3 --cpu-baseline 0 --configs 0 --handback 0 --two-part 0` (PIHNA, K(119), 1 GPU).\n")
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 for f in glob.glob(d + "/stats/**/*kernel_stats.csv", recursive=True):
     print("## kernel-trace --stats\n\n| kernel | calls | total ns | average ns | % |\n|---|---|---|---|---|")
