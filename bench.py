@@ -319,9 +319,136 @@ def profile_numbers(n, world):
     return None, None, None
 
 
+def run_cfg5(a):
+    """BASELINE config 5 across GPUs (`--workload cfg5`): coupled_hcc + solid_system on the deforming H(n) HEX8 mesh, RCB element
+    partition + one ghost layer; one step = ONE grouped halo exchange carrying the HCC unknowns and the current coordinates of
+    the moved mesh (6 doubles per interface node), the HCC assembly on the moved mesh and one Newton assembly (residual +
+    tangent) of the solid system -- both in two parts, the interior clusters overlapping the exchange
+    (src/coupled_hcc.C:98-130 call order, src/solid_system.C:103-123 mesh move).  Prints one JSON line on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from rdcfes_amd import AssemblyContext, SolidMaterial, SolidParams, hcc_params_from_dict, partition, synth
+    from rdcfes_amd.context import FIELD_ELEM_FIBRE, FIELD_OLD_SOLUTION, FIELD_UNDEFORMED_XYZ
+    from rdcfes_amd.halo import HaloExchange
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the assembly path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = a.n if a.n != 119 else 126
+    conn, Xu = synth.hex_mesh(n, jitter=0.1, order="lex")
+    x = Xu + synth.solid_displacement(Xu, amp=0.02 / n * 8)
+    uh = synth.hcc_fields(Xu)
+    ph = hcc_params_from_dict(synth.hcc_param_dict("full"))
+    em = (np.linalg.norm(Xu[conn].mean(axis=1) - 0.5, axis=1) < 0.3).astype(np.int32)
+    mats = [SolidMaterial(2.0e3, 0.4, 0.0, (0.0, 0.0, 0.0)), SolidMaterial(2.0e3, 0.4, 0.0, (0.3, 0.3, 0.3))]
+    se, ss = synth.boundary_sides(8, conn, Xu, 2, 0.0)
+    sp = SolidParams(0.4, 1.0e8, 0, 0)
+    n_elem_global, n_node_global = conn.shape[0], Xu.shape[0]
+    part = partition.partition_rcb(Xu[conn].mean(axis=1), world)
+    lp = partition.build_local(conn, Xu, part, rank, world)
+    ng, eg = lp.node_global, lp.elem_global
+    g2l_e = np.full(n_elem_global, -1, dtype=np.int64)
+    g2l_e[eg] = np.arange(eg.size)
+    keep = g2l_e[se] >= 0                                            # boundary sides of the local elements
+    l_se, l_ss = g2l_e[se[keep]], ss[keep]
+    main_s, halo_s = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    hcc, sol = AssemblyContext(local_rank), AssemblyContext(local_rank)
+    for c in (hcc, sol):
+        c.set_stream(main_s.cuda_stream)
+        c.set_option("interior_nodes", int(lp.n_interior) if a.overlap else -1)
+        c.mesh_upload(8, lp.conn, x[ng], 3, n_owned=lp.n_owned)
+    u_t = torch.from_numpy(np.ascontiguousarray(uh[ng])).to(dev)
+    hcc.field_bind_device(FIELD_OLD_SOLUTION, u_t.data_ptr(), u_t.numel())
+    sol.field_upload(FIELD_UNDEFORMED_XYZ, Xu[ng])
+    sol.field_upload(FIELD_ELEM_FIBRE, np.tile([0.0, 0.0, 1.0], (eg.size, 1)))
+    sol.solid_set_materials(em[eg], mats)
+    sol.solid_set_sides(l_se, l_ss, np.zeros((l_se.size, 3)))
+    x_sol, x_hcc = sol.coords_tensor(), hcc.coords_tensor()
+    hx = HaloExchange(lp, 6, dev) if world > 1 else None
+    overlap = bool(a.overlap) and lp.n_interior > 0
+    del conn, Xu, x, uh, em
+
+    def step():
+        if overlap:
+            halo_s.wait_stream(main_s)
+            hcc.assemble_hcc_part(ph, 1, main_s.cuda_stream)             # interior clusters: no ghost value, no ghost coordinate
+            sol.solid_assemble_part(sp, True, 1, main_s.cuda_stream)
+            with torch.cuda.stream(halo_s):
+                if hx is not None:
+                    hx.exchange_many([u_t, x_sol])                       # one message per peer: HCC unknowns + current coordinates
+                x_hcc[lp.n_owned:].copy_(x_sol[lp.n_owned:])             # the HCC system runs on the same moved mesh
+            hcc.assemble_hcc_part(ph, 2, halo_s.cuda_stream)
+            sol.solid_assemble_part(sp, True, 2, halo_s.cuda_stream)
+            main_s.wait_stream(halo_s)
+            return
+        if hx is not None:
+            hx.exchange_many([u_t, x_sol])
+        x_hcc[lp.n_owned:].copy_(x_sol[lp.n_owned:])
+        hcc.assemble_hcc(ph)
+        sol.solid_assemble(sp, True)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    fence()
+    for c in (hcc, sol):
+        c.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    t_host = time.perf_counter() - t0
+    fence()
+    dt = time.perf_counter() - t0
+    k_hcc, k_sol = sum(hcc.timing_samples_ms()) / a.steps, sum(sol.timing_samples_ms()) / a.steps
+    stats = torch.tensor([dt, k_hcc, k_sol, t_host / a.steps * 1e6, float(hx.bytes_per_step if hx else 0), float(lp.conn.shape[0]) / max(lp.n_elem_owned, 1),
+                          float(lp.n_interior) / max(lp.n_owned, 1), float(hcc.part1_nodes()) / max(lp.n_owned, 1)], dtype=torch.float64,
+                         device="cpu" if (world > 1 and a.backend != "nccl") else dev)
+    smin = stats.clone()
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(smin, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        dt = float(stats[0])
+        _, nnz_h = hcc.csr_dims()
+        out = {"metric": "elements_assembled_per_sec", "value": n_elem_global * a.steps / dt, "unit": "elements/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"cfg5: coupled HCC + SolidSystem on the deforming HEX8 mesh H({n}): {n_elem_global} hexes, {n_node_global} nodes; "
+                                      "one step = one grouped halo (HCC unknowns + current coordinates) + HCC assembly (all rates on) + one Newton "
+                                      "assembly (residual + tangent, penalty sides); an element counts once per step",
+                          "parallelism": (f"element partition x{world} (RCB), 1 ghost layer, halo p2p over " + ("RCCL" if a.backend == "nccl" else "gloo (host-staged rehearsal)") +
+                                          (", overlapped with the interior clusters" if overlap else "")) if world > 1 else "single GPU" + (", two-part path forced" if overlap else ""),
+                          "rank0_local_elements": int(lp.conn.shape[0]), "rank0_nnz_per_system": int(nnz_h)},
+               "multi_gpu": {"kernel_ms_hcc_max": float(stats[1]), "kernel_ms_solid_max": float(stats[2]), "kernel_ms_hcc_min": float(smin[1]),
+                             "kernel_ms_solid_min": float(smin[2]), "host_enqueue_us_per_step_max": float(stats[3]),
+                             "halo_send_bytes_per_rank_max": float(stats[4]), "local_over_owned_elements_max": float(stats[5]),
+                             "interior_node_fraction_min": float(smin[6]), "part1_row_fraction_min": float(smin[7]),
+                             "note": "kernel_ms = HIP events around the assembly kernels of a step (both parts), per system"}}
+        print(json.dumps(out), flush=True)
+    hcc.close()
+    sol.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="pihna", choices=["pihna", "cfg5"], help="pihna = the metric's configuration (default); cfg5 = coupled "
+                    "HCC + solid on H(126) HEX8, partitioned like the PIHNA run (BASELINE config 5)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mesh-n", dest="n", type=int, default=119, help="K(n) mesh: n^3 cells x 6 tets (119 -> 10.1M tets)")
@@ -346,6 +473,8 @@ def main():
     if a.configs_only:
         print(json.dumps({"configs": extra_configs()}), flush=True)
         return
+    if a.workload == "cfg5":
+        return run_cfg5(a)
     import torch
     import torch.distributed as dist
     from rdcfes_amd import AssemblyContext, partition, pihna_params_from_dict, synth

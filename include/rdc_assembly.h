@@ -38,6 +38,7 @@
 #ifndef RDC_ASSEMBLY_H
 #define RDC_ASSEMBLY_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -277,6 +278,16 @@ int rdc_csr_download(rdc_ctx* ctx, double* val, double* rhs);
  * the copies are only enqueued on the context's stream (use pinned host memory; complete after rdc_synchronize or an
  * event of the caller) -- so the rows of part 1 of a two-part assembly can travel while part 2 is still computing. */
 int rdc_csr_download_rows(rdc_ctx* ctx, int64_t node_begin, int64_t node_end, double* val, double* rhs, int async);
+/* Pipelined hand-back (src/pihna.C:754-755 hands Ke/Fe to PETSc element by element; here whole row ranges travel while the
+ * device keeps assembling): as rdc_csr_download_rows, but the copies run on a stream of the context's own, behind the work
+ * ENQUEUED SO FAR on the context's stream and independent of anything enqueued later -- the rows of part 1 of a two-part
+ * assembly, or of the first node ranges of any assembly, are inserted into the PETSc matrix while the next chunk is in flight.
+ * *ticket identifies the call; rdc_ticket_wait blocks the host until that chunk is in host memory (at most 16 calls in flight).
+ * Pin the destination arrays once (rdc_host_pin: hipHostRegister) or the copies are staged and serialise. */
+int rdc_csr_download_rows_async(rdc_ctx* ctx, int64_t node_begin, int64_t node_end, double* val, double* rhs, int* ticket);
+int rdc_ticket_wait(rdc_ctx* ctx, int ticket);
+int rdc_host_pin(rdc_ctx* ctx, void* host_ptr, size_t bytes);
+int rdc_host_unpin(rdc_ctx* ctx, void* host_ptr);
 /* two-part assembly: the rows of nodes [0, *n_nodes) are complete after "part" = 1 (whole workgroups inside the
  * interior; 0 when the active kernel path cannot launch sub-ranges).  After a part-1 assemble call the value is what
  * THAT call completed -- the kernel path, and with it the split, depends on the model, the parameter values and the

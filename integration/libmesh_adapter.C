@@ -56,8 +56,11 @@ struct Binding {
   std::vector<dof_id_type> local_to_global_node;   // local node id -> libMesh node id (owned first, then ghosts)
   std::vector<dof_id_type> elem_ids;               // binding element -> libMesh element id (local elements + ghost layer)
   std::vector<PetscInt> row_ptr, col_glob;         // owned-row CSR with GLOBAL dof column ids
+  std::vector<PetscInt> row_glob;                  // global dof id of owned row r = local node * nvar + var
   std::vector<double> val, rhs, u_old;
   dof_id_type n_owned = 0;
+  bool pinned = false;                             // val / rhs registered with the HIP runtime (rdc_host_pin): async chunk copies
+  bool pattern_frozen = false;                     // MAT_NEW_NONZERO_LOCATIONS switched off after the first assembly
 };
 
 static std::map<std::string, Binding> g_bindings;
@@ -134,6 +137,9 @@ static Binding& bind(EquationSystems& es, const std::string& name, unsigned int 
     B.col_glob[k] = (PetscInt)nd.dof_number(sys.number(), cl[k] % nvar, 0);
   }
   B.val.resize(nnz); B.rhs.resize(n_rows); B.u_old.resize(nvar * B.local_to_global_node.size());
+  B.row_glob.resize(n_rows);
+  for (int64_t r = 0; r < n_rows; r++)
+    B.row_glob[r] = (PetscInt)mesh.node_ref(B.local_to_global_node[r / nvar]).dof_number(sys.number(), r % nvar, 0);
   return B;
 }
 
@@ -162,6 +168,82 @@ static void push_results(const EquationSystems& es, TransientLinearImplicitSyste
   }
 }
 
+// The same hand-back, pipelined (es.parameters "rdc/handback_chunks" > 1; mirrored and tested in rdcfes_amd/host/rdc_host.h,
+// detail::pull_results_chunked): the node range is cut into chunks, two chunk downloads are kept in flight on the context's
+// copy stream (rdc_csr_download_rows_async: behind the work enqueued so far, independent of later work), and every chunk is
+// inserted while the next travels.  The nvar rows of a node share one column set and lie back to back in the CSR array, so
+// they are ONE dense nvar x ncols block for MatSetValues: one call per node block instead of one per row (rows of different
+// nodes have different column sets: a chunk as a whole is not a dense block, so it cannot be a single call).
+// After the first assembly the pattern is frozen (MAT_NEW_NONZERO_LOCATIONS off): PETSc then skips the search for new
+// locations and any pattern drift is an error instead of a silent reallocation.
+static void push_results_chunked(const EquationSystems& es, TransientLinearImplicitSystem& sys, Binding& B, unsigned int nvar, int n_chunks) {
+  Mat A = cast_ref<PetscMatrix<Number>&>(*sys.matrix).mat();
+  const MeshBase& mesh = es.get_mesh();
+  if (!B.pinned) {
+    if (rdc_host_pin(B.ctx, B.val.data(), B.val.size() * sizeof(double)) != RDC_OK) fail(B.ctx, "rdc_host_pin");
+    if (rdc_host_pin(B.ctx, B.rhs.data(), B.rhs.size() * sizeof(double)) != RDC_OK) fail(B.ctx, "rdc_host_pin");
+    B.pinned = true;
+  }
+  const int64_t n_nodes = (int64_t)B.n_owned;
+  auto bound = [&](int k) { return n_nodes * k / n_chunks; };
+  int ticket[2] = {-1, -1};
+  if (rdc_csr_download_rows_async(B.ctx, bound(0), bound(1), B.val.data(), B.rhs.data(), &ticket[0]) != RDC_OK) fail(B.ctx, "rdc_csr_download_rows_async");
+  std::vector<PetscInt> rows(nvar);
+  for (int k = 0; k < n_chunks; k++) {
+    if (k + 1 < n_chunks &&
+        rdc_csr_download_rows_async(B.ctx, bound(k + 1), bound(k + 2), B.val.data(), B.rhs.data(), &ticket[(k + 1) & 1]) != RDC_OK)
+      fail(B.ctx, "rdc_csr_download_rows_async");
+    if (rdc_ticket_wait(B.ctx, ticket[k & 1]) != RDC_OK) fail(B.ctx, "rdc_ticket_wait");
+    for (int64_t l = bound(k); l < bound(k + 1); l++) {
+      const Node& nd = mesh.node_ref(B.local_to_global_node[(size_t)l]);
+      for (unsigned int a = 0; a < nvar; a++) rows[a] = (PetscInt)nd.dof_number(sys.number(), a, 0);
+      const PetscInt b = B.row_ptr[(size_t)(l * nvar)], n = B.row_ptr[(size_t)(l * nvar) + 1] - b;
+      // rows l*nvar .. l*nvar + nvar - 1: the same n columns (B.col_glob[b ..]), values row after row from B.val[b]
+      MatSetValues(A, (PetscInt)nvar, rows.data(), n, &B.col_glob[(size_t)b], &B.val[(size_t)b], INSERT_VALUES);
+      for (unsigned int a = 0; a < nvar; a++) sys.rhs->set(rows[a], B.rhs[(size_t)(l * nvar + a)]);
+    }
+  }
+  if (!B.pattern_frozen) {   // takes effect for the NEXT assembly (this one may still have created locations)
+    MatSetOption(A, MAT_NEW_NONZERO_LOCATIONS, PETSC_FALSE);
+    B.pattern_frozen = true;
+  }
+}
+
+#if defined(PETSC_HAVE_HIP) && defined(RDC_ADAPTER_DEVICE_HANDOFF)
+// Device-pointer hand-off: with one rank and a MATSEQAIJHIPSPARSE system matrix PETSc's CSR value
+// array IS the context's (same row order, columns ascending within a row -- rdc_csr_pattern_download is what the adapter
+// preallocated from), so the hand-back is one device-to-device copy and the 5 GB never cross PCIe.  With several ranks PETSc
+// keeps the diagonal and the off-diagonal block of MPIAIJ separately; the chunked host path above stays the portable one.
+#include <hip/hip_runtime_api.h>
+static bool push_results_device(TransientLinearImplicitSystem& sys, Binding& B) {
+  Mat A = cast_ref<PetscMatrix<Number>&>(*sys.matrix).mat();
+  PetscBool is_seq_hip = PETSC_FALSE;
+  PetscObjectTypeCompare((PetscObject)A, MATSEQAIJHIPSPARSE, &is_seq_hip);
+  if (!is_seq_hip) return false;
+  double *d_val = nullptr, *d_rhs = nullptr;
+  if (rdc_csr_values_device_ptr(B.ctx, &d_val, &d_rhs) != RDC_OK) fail(B.ctx, "rdc_csr_values_device_ptr");
+  PetscScalar* a = nullptr;
+  MatSeqAIJHIPSPARSEGetArrayWrite(A, &a);                 // device pointer of the CSR values, write access
+  if (rdc_synchronize(B.ctx) != RDC_OK) fail(B.ctx, "rdc_synchronize");
+  if (hipMemcpy(a, d_val, B.val.size() * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) libmesh_error_msg("device hand-off copy failed");
+  MatSeqAIJHIPSPARSERestoreArrayWrite(A, &a);
+  // the rhs is small (nvar doubles per node): through the host as before
+  if (rdc_csr_download(B.ctx, nullptr, B.rhs.data()) != RDC_OK) fail(B.ctx, "rdc_csr_download");
+  for (size_t r = 0; r < B.rhs.size(); r++) sys.rhs->set(B.row_glob[r], B.rhs[r]);
+  return true;
+}
+#endif
+
+// what every assemble_<model> callback does with the finished rows
+static void hand_back(const EquationSystems& es, TransientLinearImplicitSystem& sys, Binding& B, unsigned int nvar) {
+#if defined(PETSC_HAVE_HIP) && defined(RDC_ADAPTER_DEVICE_HANDOFF)
+  if (B.pattern_frozen && push_results_device(sys, B)) return;   // from the second assembly on (the first one creates the pattern on the host path)
+#endif
+  const int chunks = es.parameters.have_parameter<int>("rdc/handback_chunks") ? es.parameters.get<int>("rdc/handback_chunks") : 8;
+  if (chunks > 1) push_results_chunked(es, sys, B, nvar, chunks);
+  else push_results(es, sys, B, nvar);
+}
+
 void assemble_pihna(EquationSystems& es, const std::string& system_name) {
   TransientLinearImplicitSystem& system = es.get_system<TransientLinearImplicitSystem>(system_name);
   libmesh_assert_equal_to(system.n_vars(), 5);
@@ -183,7 +265,7 @@ void assemble_pihna(EquationSystems& es, const std::string& system_name) {
   gather_old_solution(es, system, B, 5);
   if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
   if (rdc_assemble_pihna(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_pihna");
-  push_results(es, system, B, 5);
+  hand_back(es, system, B, 5);
 }
 
 // src/coupled_hcc.C:414-649.  The mesh is the CURRENT configuration (SolidSystem::update moved the nodes,
@@ -211,7 +293,7 @@ void assemble_hcc(EquationSystems& es, const std::string& system_name) {
   gather_old_solution(es, system, B, 3);
   if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
   if (rdc_assemble_hcc(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_hcc");
-  push_results(es, system, B, 3);
+  hand_back(es, system, B, 3);
 }
 
 // src/ripf.C:337-673: additionally reads TD vars 1, 2 (src/ripf.C:470-471) and RT var 2 (:477-478)
@@ -248,7 +330,7 @@ void assemble_ripf(EquationSystems& es, const std::string& system_name) {
   if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
   if (rdc_field_upload(B.ctx, RDC_FIELD_AUX_NODAL, aux.data(), (int64_t)aux.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(aux)");
   if (rdc_assemble_ripf(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_ripf");
-  push_results(es, system, B, 3);
+  hand_back(es, system, B, 3);
 }
 
 // current_local_solution of any nodal system at the binding's nodes -> [local node][first..first+n) per node
@@ -299,7 +381,7 @@ void assemble_adpm(EquationSystems& es, const std::string& system_name) {
   if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
   if (rdc_field_upload(B.ctx, RDC_FIELD_ELEM_TRACTS, tr.data(), (int64_t)tr.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(tracts)");
   if (rdc_assemble_adpm(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_adpm");
-  push_results(es, system, B, 3);
+  hand_back(es, system, B, 3);
 }
 
 // src/proteas.C:338-705: unknowns hos, tum, nec, vsc, oed; the nodal "AUX" system {HU, RTD} -> RDC_FIELD_AUX_NODAL
@@ -330,7 +412,7 @@ void assemble_proteas_model(EquationSystems& es, const std::string& system_name)
   if (rdc_field_upload(B.ctx, RDC_FIELD_OLD_SOLUTION, B.u_old.data(), (int64_t)B.u_old.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload");
   if (rdc_field_upload(B.ctx, RDC_FIELD_AUX_NODAL, aux.data(), (int64_t)aux.size()) != RDC_OK) fail(B.ctx, "rdc_field_upload(aux)");
   if (rdc_assemble_proteas(B.ctx, &p) != RDC_OK) fail(B.ctx, "rdc_assemble_proteas");
-  push_results(es, system, B, 5);
+  hand_back(es, system, B, 5);
 }
 
 // ---- SolidSystem: FEMSystem::assembly() replaced wholesale -------------------------------------------------------

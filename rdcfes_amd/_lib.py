@@ -51,6 +51,10 @@ SIGNATURES = {
     "rdc_csr_download": (C.c_int, [ctx_p, P(dbl), P(dbl)]),
     "rdc_csr_download_rows": (C.c_int, [ctx_p, i64, i64, C.c_void_p, C.c_void_p, C.c_int]),
     "rdc_part1_nodes": (C.c_int, [ctx_p, P(i64)]),
+    "rdc_csr_download_rows_async": (C.c_int, [ctx_p, i64, i64, C.c_void_p, C.c_void_p, P(C.c_int)]),
+    "rdc_ticket_wait": (C.c_int, [ctx_p, C.c_int]),
+    "rdc_host_pin": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t]),
+    "rdc_host_unpin": (C.c_int, [ctx_p, C.c_void_p]),
     "rdc_assemble_adpm": (C.c_int, [ctx_p, C.c_void_p]),
     "rdc_assemble_proteas": (C.c_int, [ctx_p, C.c_void_p]),
     "rdc_clamp_nonnegative": (C.c_int, [ctx_p, C.c_int]),

@@ -57,6 +57,12 @@ struct rdc_ctx {
   int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
   int scl_interior = -1, scl_n_wg_interior = 0;   // "interior_nodes" the cluster lists were built with; leading interior clusters
   int64_t scl_part1_nodes = 0;
+  // chunked hand-back (rdc_csr_download_rows_async): a copy stream of the context's own and a small pool of completion events
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_fence = nullptr;            // recorded on the context's stream at call time: the copy starts behind the work enqueued so far
+  static constexpr int N_TICKETS = 16;
+  hipEvent_t ticket[N_TICKETS] = {};
+  int next_ticket = 0;
   hipEvent_t solid_part1_event = nullptr;   // recorded behind part 1 of a two-part solid assembly (the sides of part 2 wait for it)
   bool solid_part1_pending = false;
   int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
@@ -639,6 +645,9 @@ int rdc_ctx_destroy(rdc_ctx* c) {
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->pack_event) (void)hipEventDestroy(c->pack_event);
   if (c->solid_part1_event) (void)hipEventDestroy(c->solid_part1_event);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  if (c->copy_fence) (void)hipEventDestroy(c->copy_fence);
+  for (hipEvent_t e : c->ticket) if (e) (void)hipEventDestroy(e);
   delete c;
   return RDC_OK;
 }
@@ -1062,6 +1071,10 @@ int rdc_solid_assemble(rdc_ctx* c, const rdc_solid_params* p, int request_jacobi
     a.brow = nullptr;
   }
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  if (a.sides_wait) {   // part 2 starts behind part 1 (its penalty sides add into rows of both parts); in a step it follows the halo exchange anyway
+    RDC_HIP(c, hipStreamWaitEvent(c->stream, a.sides_wait, 0));
+    a.sides_wait = nullptr;
+  }
   if (c->timing) {
     if ((rc = next_event_pair(c, &ev_start, &ev_stop))) return rc;
     RDC_HIP(c, hipEventRecord(ev_start, c->stream));
@@ -1106,6 +1119,55 @@ int rdc_csr_download_rows(rdc_ctx* c, int64_t node_begin, int64_t node_end, doub
     RDC_HIP(c, hipMemcpyAsync(rhs + node_begin * nv, (const double*)c->rhs.p + node_begin * nv,
                               (size_t)((node_end - node_begin) * nv) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (!async) RDC_HIP(c, hipStreamSynchronize(c->stream));
+  return RDC_OK;
+}
+
+int rdc_csr_download_rows_async(rdc_ctx* c, int64_t node_begin, int64_t node_end, double* val, double* rhs, int* ticket) {
+  if (!c || !ticket) return RDC_ERR_INVALID;
+  if (!c->have_mesh) return fail(c, RDC_ERR_STATE, "no mesh uploaded");
+  if (node_begin < 0 || node_end < node_begin || node_end > c->prep.n_owned) return fail(c, RDC_ERR_INVALID, "bad node range");
+  int rc = set_device(c);
+  if (rc) return rc;
+  if (!c->copy_stream) RDC_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_fence) RDC_HIP(c, hipEventCreateWithFlags(&c->copy_fence, hipEventDisableTiming));
+  const int t = c->next_ticket;
+  c->next_ticket = (t + 1) % rdc_ctx::N_TICKETS;
+  if (!c->ticket[t]) RDC_HIP(c, hipEventCreateWithFlags(&c->ticket[t], hipEventDisableTiming | hipEventBlockingSync));
+  else RDC_HIP(c, hipEventSynchronize(c->ticket[t]));   // the slot's previous copy (16 calls ago) has certainly been consumed
+  // the rows must be complete in what has been enqueued on the context's stream so far; work enqueued later (part 2) is not waited for
+  RDC_HIP(c, hipEventRecord(c->copy_fence, c->stream));
+  RDC_HIP(c, hipStreamWaitEvent(c->copy_stream, c->copy_fence, 0));
+  const int64_t nv = c->prep.nvar;
+  const int64_t v0 = nv * nv * c->prep.bptr[(size_t)node_begin], v1 = nv * nv * c->prep.bptr[(size_t)node_end];
+  if (val && v1 > v0)
+    RDC_HIP(c, hipMemcpyAsync(val + v0, (const double*)c->val.p + v0, (size_t)(v1 - v0) * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+  if (rhs && node_end > node_begin)
+    RDC_HIP(c, hipMemcpyAsync(rhs + node_begin * nv, (const double*)c->rhs.p + node_begin * nv,
+                              (size_t)((node_end - node_begin) * nv) * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+  RDC_HIP(c, hipEventRecord(c->ticket[t], c->copy_stream));
+  *ticket = t;
+  return RDC_OK;
+}
+
+int rdc_ticket_wait(rdc_ctx* c, int ticket) {
+  if (!c || ticket < 0 || ticket >= rdc_ctx::N_TICKETS || !c->ticket[ticket]) return c ? fail(c, RDC_ERR_INVALID, "no such ticket") : RDC_ERR_INVALID;
+  int rc = set_device(c);
+  if (rc) return rc;
+  RDC_HIP(c, hipEventSynchronize(c->ticket[ticket]));
+  return RDC_OK;
+}
+
+int rdc_host_pin(rdc_ctx* c, void* p, size_t bytes) {
+  if (!c || !p) return RDC_ERR_INVALID;
+  int rc = set_device(c);
+  if (rc) return rc;
+  RDC_HIP(c, hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return RDC_OK;
+}
+
+int rdc_host_unpin(rdc_ctx* c, void* p) {
+  if (!c || !p) return RDC_ERR_INVALID;
+  RDC_HIP(c, hipHostUnregister(p));
   return RDC_OK;
 }
 

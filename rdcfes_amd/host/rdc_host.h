@@ -226,6 +226,7 @@ class TransientLinearImplicitSystem : public ImplicitSystem {
   using ImplicitSystem::ImplicitSystem;
   NumericVector old_local_solution, older_local_solution;
   Real time = 0.0;
+  std::vector<int64_t> handback_log;   // node ranges [n0, n1) in the order the chunked hand-back delivered them ("rdc/handback_chunks")
   void attach_assemble_function(AssembleFn f) { assemble_fn_ = f; }
   Number old_solution(dof_id_type dof) const { return old_local_solution((int64_t)dof); }
   SparseMatrix& get_system_matrix() { return matrix_storage; }
@@ -392,7 +393,40 @@ inline int TransientLinearImplicitSystem::solve(Real tol, int max_its) {
 
 // ---- the drop-in callbacks: same signature as the reference's static assemble_* -----------------
 namespace detail {
+// Hand-back of the assembled owned rows (what add_matrix / add_vector did element by element, src/pihna.C:754-755).
+// "rdc/handback_chunks" > 1 (es.parameters, int) selects the pipelined form the libMesh adapter uses (push_results_chunked in
+// integration/libmesh_adapter.C): the node range is cut into chunks, two chunk downloads are kept in flight on the context's
+// copy stream, and every chunk is consumed (there: one MatSetValues per node block; here: `consume`) while the next travels.
+template <class Consume>
+inline void pull_results_chunked(rdc_ctx* c, TransientLinearImplicitSystem& sys, int n_chunks, Consume&& consume) {
+  std::vector<double>& val = sys.matrix_storage.val;
+  std::vector<double>& rhs = sys.rhs_storage.raw();
+  const int64_t nv = (int64_t)sys.n_vars();
+  const int64_t n_nodes = (int64_t)rhs.size() / nv;
+  check(c, rdc_host_pin(c, val.data(), val.size() * sizeof(double)), "rdc_host_pin");
+  check(c, rdc_host_pin(c, rhs.data(), rhs.size() * sizeof(double)), "rdc_host_pin");
+  auto bound = [&](int k) { return n_nodes * k / n_chunks; };
+  int ticket[2] = {-1, -1};
+  check(c, rdc_csr_download_rows_async(c, bound(0), bound(1), val.data(), rhs.data(), &ticket[0]), "rdc_csr_download_rows_async");
+  for (int k = 0; k < n_chunks; k++) {
+    if (k + 1 < n_chunks)
+      check(c, rdc_csr_download_rows_async(c, bound(k + 1), bound(k + 2), val.data(), rhs.data(), &ticket[(k + 1) & 1]), "rdc_csr_download_rows_async");
+    check(c, rdc_ticket_wait(c, ticket[k & 1]), "rdc_ticket_wait");
+    consume(bound(k), bound(k + 1));     // rows of nodes [bound(k), bound(k + 1)) are in host memory
+  }
+  check(c, rdc_host_unpin(c, val.data()), "rdc_host_unpin");
+  check(c, rdc_host_unpin(c, rhs.data()), "rdc_host_unpin");
+}
 inline void pull_results(rdc_ctx* c, TransientLinearImplicitSystem& sys) {
+  const Parameters& P = sys.get_equation_systems().parameters;
+  const int chunks = P.have_parameter<int>("rdc/handback_chunks") ? P.get<int>("rdc/handback_chunks") : 1;
+  if (chunks > 1) {
+    // the mirror's matrix IS the destination array: the consumer only records which rows it was handed, in which order
+    std::vector<int64_t>& log = sys.handback_log;
+    log.clear();
+    pull_results_chunked(c, sys, chunks, [&](int64_t n0, int64_t n1) { log.push_back(n0); log.push_back(n1); });
+    return;
+  }
   check(c, rdc_csr_download(c, sys.matrix_storage.val.data(), sys.rhs_storage.raw().data()), "rdc_csr_download");
 }
 inline Real getR(const Parameters& p, const char* k) { return p.get<Real>(k); }

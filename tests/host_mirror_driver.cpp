@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
       std::ifstream in(dir + "/params.txt");
       std::string key, val;
       while (in >> key >> val) {
-        if (key == "RT_dose/total/max") es.parameters.set<int>(key) = std::atoi(val.c_str());
+        if (key == "RT_dose/total/max" || key == "rdc/handback_chunks") es.parameters.set<int>(key) = std::atoi(val.c_str());
         else es.parameters.set<Real>(key) = std::atof(val.c_str());
       }
     }
@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
       csv.precision(17);
       save_solution_ripf(csv, es);
     }
+    if (!model->handback_log.empty()) write_raw(dir + "/handback_log.bin", model->handback_log);
     write_raw(dir + "/val.bin", model->matrix->val);
     write_raw(dir + "/rhs.bin", model->rhs->raw());
     write_raw(dir + "/row_ptr.bin", model->matrix->row_ptr);

@@ -208,3 +208,33 @@ def test_cfg4_eightway_partition_of_k119():
             ctx.set_option("part", 0)
             v_2, r_2 = ctx.csr_download()
             assert rel(v_2, v_rg) < 1e-13 and rel(r_2, r_rg) < 1e-13
+
+
+# ---- cfg4 / the metric's configuration at full size against the oracle ---------------------------------------------------
+def test_headline_k119_shipped_params_default_kernel_against_oracle(oracle):
+    """The exact bench.py workload -- PIHNA, K(119) = 10,110,954 TET4, run/PIHNA/input.dat parameters, the default kernel
+    (element visits, k_tet4_ev) -- against the oracle on the whole mesh: all 639,395,950 CSR values and 8,640,000 rhs entries
+    ("same mesh, same fields ... parity residual"; bench.py prints the same two numbers as "parity")."""
+    conn, xyz = synth.kuhn_tet_mesh(119, order="lex")
+    assert conn.shape[0] == 10110954 and xyz.shape[0] == 1728000
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    pattern = oracle.build_pattern(4, conn, xyz.shape[0], xyz.shape[0], 5)[:2]
+    _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_PIHNA, 4, conn, xyz, 5, p, u_old=u, pattern=pattern, threads=THREADS)
+    with AssemblyContext(0) as ctx:
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val, rhs = ctx.csr_download()
+        rp, col = ctx.csr_pattern()
+    assert np.array_equal(rp, pattern[0]) and np.array_equal(col, pattern[1])
+    del rp, col, pattern
+
+    def rel_chunked(a, b):
+        num = den = 0.0
+        for i in range(0, a.size, 1 << 24):
+            d = a[i:i + (1 << 24)] - b[i:i + (1 << 24)]
+            num += float(np.dot(d, d))
+            den += float(np.dot(b[i:i + (1 << 24)], b[i:i + (1 << 24)]))
+        return (num / den) ** 0.5
+    assert rel_chunked(rhs, rhs0) < TOL and rel_chunked(val, val0) < TOL

@@ -141,3 +141,25 @@ def test_time_step_through_host_mirror(oracle, driver, tmp_path):
     A = sp.csr_matrix((val0, col0, rp0), shape=(rhs0.size, rhs0.size))
     x = spla.spsolve(A.tocsc(), rhs0)
     assert np.linalg.norm(sol - x) / np.linalg.norm(x) < 1e-8
+
+
+@pytest.mark.parametrize("chunks", [2, 7])
+def test_chunked_handback_through_host_mirror(oracle, driver, tmp_path, chunks):
+    """"rdc/handback_chunks" > 1: the pipelined hand-back of the libMesh adapter (rdc_csr_download_rows_async on the context's
+    copy stream, two chunks in flight, rdc_ticket_wait, one consumer call per chunk) mirrored in rdc_host.h: every node range
+    is delivered once, in order, into the same positions of the matrix / rhs arrays as the whole download."""
+    conn, xyz = synth.kuhn_tet_mesh(7, order="random")
+    from rdcfes_amd.params import PIHNA_DEFAULTS
+    d = {**PIHNA_DEFAULTS, **synth.pihna_param_dict("shipped"), "rdc/handback_chunks": chunks}
+    u = synth.pihna_fields(xyz)
+    _write_case(tmp_path, conn, xyz, u, d)
+    r = subprocess.run([str(driver), str(tmp_path), "pihna", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    log = np.fromfile(tmp_path / "handback_log.bin", dtype=np.int64).reshape(-1, 2)
+    nn = xyz.shape[0]
+    assert log.shape[0] == chunks and log[0, 0] == 0 and log[-1, 1] == nn
+    assert np.array_equal(log[1:, 0], log[:-1, 1]) and np.all(log[:, 1] >= log[:, 0])      # a partition of [0, n_nodes), in order
+    val, rhs = np.fromfile(tmp_path / "val.bin"), np.fromfile(tmp_path / "rhs.bin")
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10

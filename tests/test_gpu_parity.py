@@ -535,13 +535,15 @@ def test_two_part_assembly_ripf_element_visits(oracle):
 
 
 def test_two_part_assembly_fallback_paths():
-    """Paths that cannot launch sub-ranges (HEX8 generic kernels, the coloured strategy) write nothing in part 1 and
-    everything in part 2 -- the contract rdc_assembly.h states for rdc_set_option("part")."""
+    """Paths that cannot launch sub-ranges (the HEX8 pair kernels, the coloured strategy) write nothing in part 1 and
+    everything in part 2 -- the contract rdc_assembly.h states for rdc_set_option("part").  (The HEX8 cluster kernels do
+    launch sub-ranges since round 3: tests/test_gpu_cfg5_parts.py.)"""
     conn, xyz = synth.hex_mesh(6, jitter=0.1, order="random")
     u = synth.hcc_fields(xyz)
     p = hcc_params_from_dict(synth.hcc_param_dict("full"))
-    for nen, strategy in [(8, SCATTER_ROWGATHER), (8, SCATTER_COLOURED)]:
+    for nen, strategy, hex_kernel in [(8, SCATTER_ROWGATHER, 1), (8, SCATTER_COLOURED, 0)]:
         with AssemblyContext(0) as ctx:
+            ctx.set_option("hex_kernel", hex_kernel)     # 1 = (node, element) pair kernels
             ctx.set_scatter(strategy)
             ctx.mesh_upload(nen, conn, xyz, 3)
             ctx.field_upload(FIELD_OLD_SOLUTION, u)
@@ -556,6 +558,7 @@ def test_two_part_assembly_fallback_paths():
             ctx.assemble_hcc(p)
             vala, rhsa = ctx.csr_download()
             assert np.array_equal(vala, val1) and np.array_equal(rhsa, rhs1)     # untouched
+            assert ctx.part1_nodes() == 0
             ctx.set_option("part", 2)
             ctx.assemble_hcc(p)
             valb, rhsb = ctx.csr_download()
