@@ -96,6 +96,7 @@ struct LaunchArgs {
   ClDev cl;              // HEX8, three unknowns: cluster lists (n_wg = 0: not available / not wanted)
   bool use_ev = false;   // element-visit kernel allowed for this call
   int opt_ev_occ = 3;
+  int opt_evc_occ = 2;
   int opt_ev_persist = 0, ev_grid = 0;   // persistent form of the element-visit kernel (k_tet4_evp) and its grid (workgroups resident at once)
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;

@@ -61,15 +61,9 @@ RDC_HD void tet4_visit(const typename M::K& k, const double (&X)[4][3], const do
       else { GF[g][0] = 0.0; GF[g][1] = 0.0; GF[g][2] = 0.0; }
     }
   }
-  // ---- what depends on the row vertex: dd_i[j] = grad phi_j . grad phi_i, gk_i[g] = grad f_g . grad phi_i ------------------
-  double dd[4][4], gk[4][NG];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) dd[i][j] = (j < i) ? dd[j][i] : G[j][0] * G[i][0] + G[j][1] * G[i][1] + G[j][2] * G[i][2];
-#pragma unroll
-    for (int g = 0; g < NG; g++) gk[i][g] = GF[g][0] * G[i][0] + GF[g][1] * G[i][1] + GF[g][2] * G[i][2];
-  }
+  // ---- what depends on the row vertex -- dd_i[j] = grad phi_j . grad phi_i, gk_i[g] = grad f_g . grad phi_i -- is formed where
+  // a row is emitted (3 FMAs each) rather than kept for the whole visit: 16 + 4 NG doubles fewer live registers
+  // (Ripf: 232 -> 192 registers; 1.48 -> 1.42 ms on K(94))
   // ---- point states at c, h_0..h_3 (point index q: 0 = c, 1 + k = h_k) ---------------------------------------------------
   typename M::Pt pt[5];
   {
@@ -131,10 +125,15 @@ RDC_HD void tet4_visit(const typename M::K& k, const double (&X)[4][3], const do
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (i < r) {
+        double gk[NG], dd[4];
+#pragma unroll
+        for (int g = 0; g < NG; g++) gk[g] = GF[g][0] * G[i][0] + GF[g][1] * G[i][1] + GF[g][2] * G[i][2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) dd[j] = G[j][0] * G[i][0] + G[j][1] * G[i][1] + G[j][2] * G[i][2];
         double fe = Rs + Rh[i] * (1.0 / 3.0);
 #pragma unroll
         for (int g = 0; g < NG; g++)
-          if (M::hasRG(a, g)) fe += RGs[g] * gk[i][g];
+          if (M::hasRG(a, g)) fe += RGs[g] * gk[g];
         sink.fe(a, i, fe);
 #pragma unroll
         for (int b = 0; b < NV; b++) {
@@ -148,8 +147,8 @@ RDC_HD void tet4_visit(const typename M::K& k, const double (&X)[4][3], const do
             if (M::hasA(a, b)) v = (j == i) ? Sb[b] + 4.0 * tb[b][i] : Sb[b] + tb[b][i] + tb[b][j];
 #pragma unroll
             for (int g = 0; g < NG; g++)
-              if (M::hasB(a, b, g)) v += gk[i][g] * (FS[b][g] + fb[b][g][j]);
-            if (M::hasD(a, b)) v += dd[i][j] * Ds[b];
+              if (M::hasB(a, b, g)) v += gk[g] * (FS[b][g] + fb[b][g][j]);
+            if (M::hasD(a, b)) v += dd[j] * Ds[b];
             sink.ke(a, b, i, j, v);
           }
         }

@@ -151,10 +151,11 @@ hipError_t launch_tet4_evc(const LaunchArgs& a, const typename M::K& k) {
   constexpr int NE = evc_blocks<M>(), NP = EvcRec<M>::N / 2;
   const size_t acc = (size_t)NE * ev::NBP + ((M::NV * ev::MAXN + 1) & ~1) + (size_t)NP * E.nls * 2;
   const size_t lds_bytes = sizeof(double) * (acc > E.max_out_doubles ? acc : E.max_out_doubles);
-#define RDC_EVC(MODE)                                                                                                   \
-  hipLaunchKernelGGL((k_tet4_evc<M, MODE, 2>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
+#define RDC_EVC(MODE, MINW)                                                                                                \
+  hipLaunchKernelGGL((k_tet4_evc<M, MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
                      E.vslot, E.ntab, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
-  if (a.exp_mode == M::FAST_EXP_MODE) RDC_EVC(M::FAST_EXP_MODE); else RDC_EVC(0);
+  if (a.opt_evc_occ == 3) { if (a.exp_mode == M::FAST_EXP_MODE) RDC_EVC(M::FAST_EXP_MODE, 3); else RDC_EVC(0, 3); }
+  else { if (a.exp_mode == M::FAST_EXP_MODE) RDC_EVC(M::FAST_EXP_MODE, 2); else RDC_EVC(0, 2); }
 #undef RDC_EVC
   return hipGetLastError();
 }
