@@ -121,7 +121,7 @@ struct HostPrepEv {
   std::vector<Desc> desc;
   std::vector<uint32_t> nlist;       // [n_wg][nls] node ids, the owned ones first, padded with the first
   std::vector<uint32_t> vloc;        // [n_wg][256] four 8-bit list positions of the visit's vertices, owned first; ~0u = none
-  std::vector<uint32_t> vslot;       // [n_wg][256][4]: byte j of word i = column slot of vertex j in the row of vertex i
+  std::vector<uint32_t> vslot;       // [n_wg][256][2]: 4-bit column slot of vertex j in the row of vertex i at bits 16 (i & 1) + 4 j of word i / 2
   std::vector<Node> ntab;            // [n_wg][16]
   std::vector<uint8_t> bpart;        // [n_wg][256]: mirror block (column node -> row node) of block t = slot * 16 + node when the column node is another node of the cluster, else t itself
   // statistics: element visits and (row, visit) pairs over all workgroups

@@ -192,7 +192,7 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
   E.nls = (mx + 63) & ~63;
   E.nlist.assign((size_t)nwg * E.nls, 0);
   E.vloc.assign((size_t)nwg * BLOCK, 0xFFFFFFFFu);
-  E.vslot.assign((size_t)nwg * BLOCK * 4, 0);
+  E.vslot.assign((size_t)nwg * BLOCK * 2, 0);
   E.ntab.assign((size_t)nwg * MAXN, HostPrepEv::Node{0, 0, 0, 0, 0});
   E.bpart.assign((size_t)nwg * NBP, 0);
   std::vector<int64_t> rows_w((size_t)nwg, 0), conf_w((size_t)nwg, 0), pass_w((size_t)nwg, 0), instr_w((size_t)nwg, 0);
@@ -458,10 +458,13 @@ std::string prep_build_ev(const HostPrep& P, const uint32_t* conn, size_t lds_bu
       E.vloc[(size_t)w * BLOCK + lane] = packed;
       rows_w[(size_t)w] += v.r;
       for (int i = 0; i < v.r; i++) {
-        uint32_t word = 0;
-        for (int j = 0; j < 4; j++)
-          word |= (uint32_t)P.eslot[(size_t)v.e * 16 + (size_t)perm[i] * 4 + (size_t)perm[j]] << (8 * j);
-        E.vslot[((size_t)w * BLOCK + lane) * 4 + (size_t)i] = word;
+        uint32_t half = 0;   // four 4-bit slots (a row has at most 16 node blocks): 16 bits per row, two rows per word
+        for (int j = 0; j < 4; j++) {
+          const uint32_t sl = P.eslot[(size_t)v.e * 16 + (size_t)perm[i] * 4 + (size_t)perm[j]];
+          if (sl > 15) wfail = true;
+          half |= (sl & 15u) << (4 * j);
+        }
+        E.vslot[((size_t)w * BLOCK + lane) * 2 + (size_t)(i >> 1)] |= half << (16 * (i & 1));
         if (li[i] >= cl.size()) wfail = true;
       }
     }

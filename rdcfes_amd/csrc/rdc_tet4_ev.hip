@@ -43,14 +43,23 @@ __global__ void __launch_bounds__(256, MINW)
 k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
-          double* __restrict__ rhs, const int nls, const int wg_begin) {
+          double* __restrict__ rhs, const int nls, const int wg_begin, const int xcd_n) {
   constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
   constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP | R: 5 x MAXN | records: NP x nls x 16 B]
   __shared__ HostPrepEv::Node snode[MAXN];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-  int w = (int)blockIdx.x + wg_begin;
+  // XCD-aware order: consecutive workgroup ids go to the 8 XCDs in turn (each with its own 4 MB L2), consecutive CLUSTERS are
+  // neighbours in the mesh (they were grown along a front) and share most of their closure nodes -- so XCD x takes the
+  // x-th eighth of the launch's clusters and walks through it in order: a cluster's node records and its neighbours' are then
+  // fetched by one L2 instead of by all eight (xcd_n = clusters of this launch, 0 = off)
+  int wl = (int)blockIdx.x;
+  if (xcd_n > 0) {
+    const int q = xcd_n >> 3, rem = xcd_n & 7, x = wl & 7;
+    wl = x * q + (x < rem ? x : rem) + (wl >> 3);
+  }
+  int w = wl + wg_begin;
   if (wg_perm) w = (int)wg_perm[w];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double* const R = lds + NM * NBP;
@@ -76,7 +85,7 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   uint32_t nid = 0;
   if (wv < rounds) nid = nlist[(size_t)w * nls + wv * 64 + lane];
   const uint32_t pl = vloc[(size_t)w * BLOCK + tid];
-  const uint4 sl = reinterpret_cast<const uint4*>(vslot)[(size_t)w * BLOCK + tid];
+  const uint2 sl = reinterpret_cast<const uint2*>(vslot)[(size_t)w * BLOCK + tid];
   const HostPrepEv::Desc d = desc[w];
   const int mirror = (int)bpart[(size_t)w * NBP + tid];   // the block whose symmetric moments are added to this one's (tid: none)
   if (tid < MAXN) snode[tid] = ntab[(size_t)w * MAXN + tid];
@@ -109,13 +118,13 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
     // the owned vertices come first: r = number of list positions below nown
     const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
     EvSink<ABL> sink;
-    const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
+    const uint32_t sw[4] = {sl.x & 0xFFFFu, sl.x >> 16, sl.y & 0xFFFFu, sl.y >> 16};   // four 4-bit column slots per row
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int a = (i < r) ? li[i] : 0;   // owned vertices come first in the node list: list position == cluster index
       sink.pr[i] = R + a;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (8 * j)) & 0xFF);   // block (a, slot): slot * 16 + a
+      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);   // block (a, slot): slot * 16 + a
     }
     if (ABL < 3) ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);   // ABL 3: no compute phase at all (data movement only)
     if (ABL == 2 && sink.sum == 1.2345e300) rhs[0] = sink.sum;  // keeps the arithmetic alive
@@ -191,7 +200,7 @@ __device__ __forceinline__ void evp_dma16(const void* g, const void* lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory", "m0");
 }
 struct EvpLists {   // per-cluster lists in LDS, filled by the loader
-  static constexpr int PL = 0, SL = 1024, MIRROR = SL + 4096, SNODE = MIRROR + 256, DESC = SNODE + 256, BYTES = DESC + 32;
+  static constexpr int PL = 0, SL = 1024, MIRROR = SL + 2048, SNODE = MIRROR + 256, DESC = SNODE + 256, BYTES = DESC + 32;
 };
 }
 
@@ -227,8 +236,8 @@ k_tet4_evp(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     char* L = lists0 + b * EvpLists::BYTES;
     evp_dma16(reinterpret_cast<const char*>(vloc) + ((size_t)w * BLOCK + lane * 4) * 4, L + EvpLists::PL);
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      evp_dma16(reinterpret_cast<const char*>(vslot) + ((size_t)w * BLOCK + q * 64 + lane) * 16, L + EvpLists::SL + q * 64 * 16);
+    for (int q = 0; q < 2; q++)   // 8 bytes of column slots per lane: two lanes per 16-byte piece
+      evp_dma16(reinterpret_cast<const char*>(vslot) + (size_t)w * BLOCK * 8 + (size_t)(q * 64 + lane) * 16, L + EvpLists::SL + q * 64 * 16);
     if (lane < 16) {
       evp_dma16(reinterpret_cast<const char*>(bpart) + (size_t)w * NBP + lane * 16, L + EvpLists::MIRROR);
       evp_dma16(reinterpret_cast<const char*>(ntab) + ((size_t)w * MAXN + lane) * 16, L + EvpLists::SNODE);
@@ -283,7 +292,7 @@ k_tet4_evp(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     // ---- element visits (phase 1 of k_tet4_ev)
     const uint32_t pl = reinterpret_cast<const uint32_t*>(L + EvpLists::PL)[tid];
     if (pl != 0xFFFFFFFFu && !(diag & 1)) {
-      const uint4 sl = reinterpret_cast<const uint4*>(L + EvpLists::SL)[tid];
+      const uint2 sl = reinterpret_cast<const uint2*>(L + EvpLists::SL)[tid];
       double X[4][3], U[4][5];
       int li[4];
 #pragma unroll
@@ -301,13 +310,13 @@ k_tet4_evp(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
       }
       const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
       EvSink<0> sink;
-      const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
+      const uint32_t sw[4] = {sl.x & 0xFFFFu, sl.x >> 16, sl.y & 0xFFFFu, sl.y >> 16};   // four 4-bit column slots per row
 #pragma unroll
       for (int a = 0; a < 4; a++) {
         const int n = (a < r) ? li[a] : 0;
         sink.pr[a] = R + n;
 #pragma unroll
-        for (int j = 0; j < 4; j++) sink.p[a][j] = lds + n + MAXN * (int)((sw[a] >> (8 * j)) & 0xFF);
+        for (int j = 0; j < 4; j++) sink.p[a][j] = lds + n + MAXN * (int)((sw[a] >> (4 * j)) & 0xF);
       }
       ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
     }
@@ -400,11 +409,11 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t lds_bytes = lds_doubles * sizeof(double);
 #define RDC_EV(MODE, MINW)                                                                                          \
   hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0)
   if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 3) {   // diagnostic builds (timing only)
 #define RDC_EVA(X)                                                                                                    \
   hipLaunchKernelGGL((k_tet4_ev<3, 3, X>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0)
     if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else RDC_EVA(3);
 #undef RDC_EVA
     return hipGetLastError();

@@ -59,7 +59,7 @@ k_tet4_evc(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
   uint32_t nid = 0;
   if (wv < rounds) nid = nlist[(size_t)w * nls + wv * 64 + lane];
   const uint32_t pl = vloc[(size_t)w * BLOCK + tid];
-  const uint4 sl = reinterpret_cast<const uint4*>(vslot)[(size_t)w * BLOCK + tid];
+  const uint2 sl = reinterpret_cast<const uint2*>(vslot)[(size_t)w * BLOCK + tid];
   const HostPrepEv::Desc d = desc[w];
   if (tid < MAXN) snode[tid] = ntab[(size_t)w * MAXN + tid];
   if (wv < rounds) {
@@ -92,13 +92,13 @@ k_tet4_evc(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     const int nown = (int)d.nown;
     const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);   // the owned vertices come first
     EvcSink<M> sink;
-    const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
+    const uint32_t sw[4] = {sl.x & 0xFFFFu, sl.x >> 16, sl.y & 0xFFFFu, sl.y >> 16};   // four 4-bit column slots per row
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int a = (i < r) ? li[i] : 0;   // list position of an owned vertex == its cluster index
       sink.pr[i] = R + a;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (8 * j)) & 0xFF);   // block (a, slot): slot * 16 + a
+      for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);   // block (a, slot): slot * 16 + a
     }
     tet4_visit<M, EXP_MODE>(k, X, U, AX, r, sink);
   }

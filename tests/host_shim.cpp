@@ -222,8 +222,8 @@ int evc_replay(const P* p, const double* xyz, const double* u, const double* aux
       }
       for (int i = 0; i < 4; i++) {
         sink.nloc[i] = i < r ? li[i] : 0;
-        const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 4 + (size_t)i];
-        for (int j = 0; j < 4; j++) sink.blk[i][j] = i < r ? (int)((word >> (8 * j)) & 0xFF) * ev::MAXN + li[i] : 0;
+        const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 2 + (size_t)(i >> 1)] >> (16 * (i & 1));
+        for (int j = 0; j < 4; j++) sink.blk[i][j] = i < r ? (int)((word >> (4 * j)) & 0xF) * ev::MAXN + li[i] : 0;
       }
       if (fastexp) tet4_visit<M, M::FAST_EXP_MODE>(k, X, U, AX, r, sink); else tet4_visit<M, 0>(k, X, U, AX, r, sink);
     }
@@ -437,9 +437,9 @@ int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double*
       }
       for (int i = 0; i < 4; i++) {
         sink.nloc[i] = i < r ? li[i] : 0;
-        const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 4 + (size_t)i];
+        const uint32_t word = E.vslot[(w * HostPrepEv::BLOCK + (size_t)x) * 2 + (size_t)(i >> 1)] >> (16 * (i & 1));   // 4-bit slots, two rows per word
         for (int j = 0; j < 4; j++) {
-          const int slot = (int)((word >> (8 * j)) & 0xFF);
+          const int slot = (int)((word >> (4 * j)) & 0xF);
           sink.blk[i][j] = i < r ? slot * ev::MAXN + li[i] : 0;     // block (node a, slot s) of the slice: s * 16 + a
           if (i < r && slot >= (int)nt[li[i]].len) return 5;
         }
