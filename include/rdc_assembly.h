@@ -206,8 +206,10 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * its owned nodes interior-first; set it BEFORE rdc_mesh_upload where possible: the work lists are then built so that
  * part 1 covers every interior row, otherwise only the workgroups that happen to lie inside [0, n)); with "part" = 1 an assemble call then writes only the rows of leading workgroups
  * inside [0, n), with "part" = 2 the remaining rows, with "part" = 0 (default) all rows.  Part 1 followed by part 2
- * gives exactly the matrix and residual of one whole call.  Paths that cannot launch sub-ranges (HEX8, the
- * coloured strategy, the solid system) write nothing in part 1 and everything in part 2.
+ * gives exactly the matrix and residual of one whole call.  The TET4 row-gather kernels and the HEX8 cluster kernels
+ * (reaction-diffusion models and the fused solid tangent; their cluster lists keep interior and near-ghost nodes apart, the
+ * penalty sides of the solid system are added by part 2 behind part 1) launch sub-ranges; the paths that cannot (the
+ * HEX8 pair kernels, the coloured strategy, the two-pass solid form) write nothing in part 1 and everything in part 2.
  * Stream contract: part 1 and part 2 of a step may be issued on DIFFERENT streams (rdc_set_stream in between).  Part 1
  * reads the values of owned nodes only, so the ghost rows of the bound fields may be rewritten (halo exchange)
  * while it runs; part 2 must be issued behind that exchange on its stream.  The library itself orders part 2 behind
