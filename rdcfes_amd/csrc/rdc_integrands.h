@@ -76,10 +76,17 @@ RDC_HD double rcp(double x) {
 // ROCm 7.2); as a call it is correct everywhere, and the general-exponent path is the rare one.
 #if defined(__HIP_DEVICE_COMPILE__) && defined(RDC_POW_INLINE)   // diagnostic builds only (tools/pow_inline_probe.sh)
 __device__ __forceinline__ static double rdc_pow(double x, double e) { return pow(x, e); }
+__device__ __forceinline__ static double rdc_pow_pos(double x, double e) { return exp(e * log(x)); }
 #elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __attribute__((noinline)) static double rdc_pow(double x, double e) { return pow(x, e); }
+// x^e for x > 0 (pow_pair: a crowding base 1 - T/K in (0, 1)) as exp(e log x): the device-library pow() spends most of its
+// ~190 instructions on being correctly rounded over the whole plane (double-double logarithm, special cases); exp and log are
+// each < 1 ulp, so the result is within |e log x| * 1.2e-16 + 2e-16 relative (<= 1e-14 for the bases that survive the
+// min-vacancy cut-offs) of it -- four orders inside the 1e-10 parity bound -- at less than half the instructions.
+__device__ __attribute__((noinline)) static double rdc_pow_pos(double x, double e) { return exp(e * log(x)); }
 #else
 static inline double rdc_pow(double x, double e) { return pow(x, e); }
+static inline double rdc_pow_pos(double x, double e) { return pow(x, e); }
 #endif
 
 // x^e for the crowding functions.  The reference calls pow(1-Te, ek) with a real exponent
@@ -94,7 +101,7 @@ RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
   else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
   else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
   else if (EXP_MODE == 25) { pm1 = x * sqrt(x); p = pm1 * x; }  // e = 2.5 (run/RIPF133/input.dat): one sqrt, no pow
-  else { p = rdc_pow(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
+  else { p = rdc_pow_pos(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
 }
 
 // =========================================================================================

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256, MINW)
 k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
-          double* __restrict__ rhs, const int nls, const int wg_begin, const int xcd_n) {
+          double* __restrict__ rhs, const int nls, const int wg_begin, const int xcd_n, const int stagger) {
   constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
   constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP | R: 5 x MAXN | records: NP x nls x 16 B]
@@ -54,6 +54,14 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   // neighbours in the mesh (they were grown along a front) and share most of their closure nodes -- so XCD x takes the
   // x-th eighth of the launch's clusters and walks through it in order: a cluster's node records and its neighbours' are then
   // fetched by one L2 instead of by all eight (xcd_n = clusters of this launch, 0 = off)
+  // Diagnostic knob ("stagger" = n): the workgroups of the first wave of the launch (three per CU start together) begin 0, n or 2 n
+  // x 1024 cycles late, by the parity of their LDS allocation (the three co-resident workgroups of a CU get different
+  // addresses), so that their load / compute / store phases do not run in lockstep
+  if (stagger > 0 && blockIdx.x < 1024u) {
+    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6);   // HW_REG_LDS_ALLOC.LDS_BASE (bits 7:0): 0 for the CU's first workgroup
+    const uint32_t slot = lds_base == 0 ? 0u : (lds_base < 144u ? 1u : 2u);
+    for (uint32_t i = 0; i < slot * (uint32_t)stagger; i++) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles each
+  }
   int wl = (int)blockIdx.x;
   if (xcd_n > 0) {
     const int q = xcd_n >> 3, rem = xcd_n & 7, x = wl & 7;
@@ -409,11 +417,11 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t lds_bytes = lds_doubles * sizeof(double);
 #define RDC_EV(MODE, MINW)                                                                                          \
   hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger)
   if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 3) {   // diagnostic builds (timing only)
 #define RDC_EVA(X)                                                                                                    \
   hipLaunchKernelGGL((k_tet4_ev<3, 3, X>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger)
     if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else RDC_EVA(3);
 #undef RDC_EVA
     return hipGetLastError();

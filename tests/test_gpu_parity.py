@@ -708,3 +708,42 @@ def test_pihna_zero_cell_sum_with_positive_vasculature(oracle, moments):
     ok, okr = ~np.isnan(val0), ~np.isnan(rhs0)
     assert ok.mean() > 0.5
     assert rel(val[ok], val0[ok]) < TOL and rel(rhs[okr], rhs0[okr]) < TOL
+
+
+@pytest.mark.gpu
+def test_part1_rows_travel_while_part2_runs():
+    """rdc_csr_download_rows_async right behind part 1: the copy starts behind the work enqueued so far and is independent of
+    part 2, which is enqueued next on the context's stream; the ticket says when the rows are in host memory."""
+    import ctypes as C
+    from rdcfes_amd import _lib
+    L = _lib.load()
+    conn, xyz = synth.kuhn_tet_mesh(14, order="lex")
+    u = synth.pihna_fields(xyz)
+    p = pihna_params_from_dict(synth.pihna_param_dict("shipped"))
+    nn = xyz.shape[0]
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("interior_nodes", int(0.5 * nn))
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna(p)
+        val0, rhs0 = ctx.csr_download()
+        rp, _ = ctx.csr_pattern()
+        val = np.full_like(val0, np.nan)
+        rhs = np.full_like(rhs0, np.nan)
+        assert L.rdc_host_pin(ctx._h, val.ctypes.data, val.nbytes) == 0 and L.rdc_host_pin(ctx._h, rhs.ctypes.data, rhs.nbytes) == 0
+        ctx.field_upload(FIELD_OLD_SOLUTION, 0.5 * u)
+        ctx.assemble_pihna(p)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.assemble_pihna_part(p, 1)
+        n1 = ctx.part1_nodes()
+        t1, t2 = C.c_int(-1), C.c_int(-1)
+        assert L.rdc_csr_download_rows_async(ctx._h, 0, n1, val.ctypes.data, rhs.ctypes.data, C.byref(t1)) == 0
+        ctx.assemble_pihna_part(p, 2)                          # enqueued behind the copy's fence, not waited for by it
+        assert L.rdc_ticket_wait(ctx._h, t1.value) == 0
+        assert np.isfinite(val[:rp[5 * n1]]).all() and np.isnan(val[rp[5 * n1]:]).all()     # exactly the rows of part 1 have landed
+        assert L.rdc_csr_download_rows_async(ctx._h, n1, nn, val.ctypes.data, rhs.ctypes.data, C.byref(t2)) == 0
+        assert L.rdc_ticket_wait(ctx._h, t2.value) == 0
+        assert L.rdc_ticket_wait(ctx._h, 15) != 0               # a ticket that was never issued
+        assert L.rdc_host_unpin(ctx._h, val.ctypes.data) == 0 and L.rdc_host_unpin(ctx._h, rhs.ctypes.data) == 0
+    assert n1 > 0
+    assert rel(val, val0) < 1e-13 and rel(rhs, rhs0) < 1e-13
