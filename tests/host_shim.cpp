@@ -314,11 +314,29 @@ int shim_ev_build(int64_t lds_budget, int64_t* stats) {
 // local row node, owned-node index and column slots the kernel will use.
 // stats[8] = workgroups, element visits, pairs, largest one-row image (doubles), owned nodes covered, largest cluster,
 // 16-lane groups of pairs, groups in which a node occurs twice
+static int64_t g_cl_interior = -1;   // "interior_nodes" of the next shim_cl_build (two-part assembly), -1 = none
+void shim_cl_set_interior(int64_t n) { g_cl_interior = n; }
+// two-part assembly: out[3] = leading clusters of interior nodes, rows complete after them, clusters mixing the two kinds (must be 0)
+int shim_cl_interior_stats(int64_t* out) {
+  const HostPrepCl& C = g_cl;
+  out[0] = C.n_wg_interior; out[1] = C.part1_nodes; out[2] = 0;
+  const int max_nodes = C.lim.max_nodes;
+  for (size_t w = 0; w < C.desc.size(); w++) {
+    int n_in = 0;
+    for (int a = 0; a < C.desc[w].nown; a++) n_in += (int64_t)C.ntab[w * max_nodes + a].node < g_cl_interior;
+    const bool interior = n_in == C.desc[w].nown;
+    if (n_in != 0 && !interior) out[2]++;                                   // a cluster holds both kinds
+    if (interior != ((int64_t)w < C.n_wg_interior)) return 1;               // the interior clusters are exactly the leading ones
+    if (!interior)
+      for (int a = 0; a < C.desc[w].nown; a++) if ((int64_t)C.ntab[w * max_nodes + a].node < C.part1_nodes) return 2;   // a row below the bound is not complete after part 1
+  }
+  return 0;
+}
 int shim_cl_build(int max_nodes, int max_pairs, int max_elems, int max_row_doubles, int pair_order, int64_t* stats) {
   HostPrepCl::Limits lim;
   stats[5] = 0;
   lim.max_nodes = max_nodes; lim.max_pairs = max_pairs; lim.max_elems = max_elems; lim.max_row_doubles = max_row_doubles; lim.pair_order = pair_order;
-  g_err = prep_build_cl(g_prep, g_conn.data(), lim, g_cl);
+  g_err = prep_build_cl(g_prep, g_conn.data(), lim, g_cl, g_cl_interior);
   if (!g_err.empty()) return 1;
   const HostPrepCl& C = g_cl;
   const int nen = g_prep.nen;

@@ -113,3 +113,30 @@ def test_hex8_cluster_replay_on_a_ghosted_partition(oracle, shim):
     _, _, val0, rhs0 = oracle.assemble(oracle.MODEL_HCC, 8, conn, xyz, 3, p, u_old=u, n_owned=n_owned)
     val, rhs = _replay(shim, 2, p, conn, xyz, u, None, None, n_owned)
     assert _rel(val, val0) < 1e-10 and _rel(rhs, rhs0) < 1e-10
+
+
+@pytest.mark.parametrize("pair_order", [0, 1])
+def test_cluster_lists_respect_interior_nodes(shim, pair_order):
+    """two-part assembly of the HEX8 cluster kernels (config 5 across GPUs): with "interior_nodes" = n the clusters never mix
+    interior nodes (< n) with the others, the interior clusters come first in the lists (part 1 = a leading sub-range), every
+    structural property of the lists holds as before, and no row below the reported part-1 bound belongs to a later cluster.
+    The node numbering is what partition.build_local produces for a rank of a 2-way split (owned nodes interior-first)."""
+    from rdcfes_amd import partition
+    conn, xyz = synth.hex_mesh(9, jitter=0.1, order="random")
+    part = partition.partition_rcb(xyz[conn].mean(axis=1), 2)
+    lp = partition.build_local(conn, xyz, part, 0, 2)
+    assert 0 < lp.n_interior < lp.n_owned
+    shim.shim_cl_set_interior(C.c_int64(lp.n_interior))
+    try:
+        st = _build(shim, 8, lp.conn, lp.xyz.shape[0], lp.n_owned, (24, 192, 64, 6198), pair_order)
+        out = (C.c_int64 * 3)()
+        assert shim.shim_cl_interior_stats(out) == 0
+    finally:
+        shim.shim_cl_set_interior(C.c_int64(-1))
+    assert st["covered"] == lp.n_owned
+    n_wg_int, part1_nodes, mixed = list(out)
+    assert mixed == 0 and 0 < n_wg_int < st["n_wg"]
+    assert 0 < part1_nodes <= lp.n_interior
+    # the split costs little: at most a few clusters more than without it
+    st0 = _build(shim, 8, lp.conn, lp.xyz.shape[0], lp.n_owned, (24, 192, 64, 6198), pair_order)
+    assert st["n_wg"] <= 1.15 * st0["n_wg"] + 2
