@@ -101,7 +101,18 @@ RDC_HD void pow_pair(double x, double e, double& p, double& pm1) {
   else if (EXP_MODE == 3) { pm1 = x * x; p = pm1 * x; }
   else if (EXP_MODE == 4) { pm1 = x * x * x; p = pm1 * x; }
   else if (EXP_MODE == 25) { pm1 = x * sqrt(x); p = pm1 * x; }  // e = 2.5 (run/RIPF133/input.dat): one sqrt, no pow
-  else { p = rdc_pow_pos(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
+  else {
+    // EXP_MODE 0: the exponent is a run-time value -- but a UNIFORM one (a kernel argument, held in scalar registers), so testing it
+    // for the cheap cases costs a scalar compare and branch per call: small integers by multiplication, 2.5 with one square
+    // root (each <= 1 ulp from pow), anything else through exp(e log x).  The dedicated instantiations above (EXP_MODE = the
+    // shipped exponent of the model) only save these branches.
+    if (e == 3.0) { pm1 = x * x; p = pm1 * x; }
+    else if (e == 2.0) { pm1 = x; p = x * x; }
+    else if (e == 2.5) { pm1 = x * sqrt(x); p = pm1 * x; }
+    else if (e == 4.0) { pm1 = x * x * x; p = pm1 * x; }
+    else if (e == 1.0) { pm1 = 1.0; p = x; }
+    else { p = rdc_pow_pos(x, e); pm1 = p * rcp(x); }  // x^(e-1) = x^e / x for x > 0 (the only domain it is called on)
+  }
 }
 
 // =========================================================================================
