@@ -194,8 +194,9 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * "moments": 1 (default) evaluates PIHNA/TET4 rows in moment form when the parameters have the shipped pattern (cell
  * transport off), 0 in coefficient form -- same sums, other association; "specialise": 0 disables that parameter-
  * pattern variant altogether; "kernel", "staged", "slim", "stagger", "prefetch", "xcd", "schedule", "block", "grid",
- * "ev_occupancy", "ev_lds", "ev_persistent" (1 = the element-visit kernel as resident workgroups walking over the clusters,
- * experimental) select alternative / diagnostic kernels.  HEX8 with three unknowns: "hex_kernel" 0 =
+ * "ev_occupancy", "ev_lds", "evc_occupancy", "ev_persistent" (1 = the element-visit kernel as two resident workgroups per CU with a
+ * loader wave), "ev_resident" (1 = as three resident workgroups per CU that load the next cluster's node list one cluster
+ * ahead) -- both experimental and slower than the default -- select alternative / diagnostic kernels.  HEX8 with three unknowns: "hex_kernel" 0 =
  * producer / consumer cluster kernel (default), 1 = (node, element) pair kernels, 2 = persistent form of the cluster
  * kernel; "solid_kernel" 0 = fused cluster kernel for HEX8 tangent requests and the two-pass form otherwise (default),
  * 1 = coloured read-modify-write, 2 = two-pass always (bitwise reproducible sums), 3 = fused (error when unavailable);
