@@ -84,6 +84,19 @@ class SolidSetup:
         return np.concatenate(es), np.concatenate(ss), np.concatenate(sd)
 
 
+def model_keys(kv: dict, keys) -> dict:
+    """The entries of a parsed input file that one model's `input()` looks up (`keys`: the `*_KEYS` map of
+    rdcfes_amd.params), as numbers.  Everything else in the file is ignored, as upstream: each `input()` asks GetPot
+    for its own names and takes the coded default for a name the file does not hold (src/pihna.C:139-235,
+    src/ripf.C:172-249, src/adpm.C:163-233, src/coupled_hcc.C input())."""
+    return {k: _real(kv, k, 0.0) for k in keys if k in kv}
+
+
+def read_model_input(path, keys) -> dict:
+    with open(path) as fh:
+        return model_keys(parse_getpot(fh.read()), keys)
+
+
 def read_solid_input(path) -> SolidSetup:
     with open(path) as fh:
         return SolidSetup(parse_getpot(fh.read()))
