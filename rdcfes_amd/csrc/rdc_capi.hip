@@ -66,6 +66,7 @@ struct rdc_ctx {
   hipEvent_t solid_part1_event = nullptr;   // recorded behind part 1 of a two-part solid assembly (the sides of part 2 wait for it)
   bool solid_part1_pending = false;
   int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
+  int opt_ev_general = 1;          // 1 = PIHNA / TET4 with any parameter values through the element-visit kernel with 22 moments; 0 = pair kernel (k_tet4_rg5<Pihna>)
   int opt_ev_resident = 0;         // 1 = k_tet4_evl (resident workgroups, next node list prefetched; experimental)
   int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
@@ -233,6 +234,8 @@ template <class M, class P>
 hipError_t launch_specialised(const LaunchArgs& a, const typename M::K& k, const P&) { return launch_rd<M>(a, k); }
 template <>
 hipError_t launch_specialised<Pihna, rdc_pihna_params>(const LaunchArgs& a, const Pihna::K& k, const rdc_pihna_params& p) {
+  // any parameter values: the element-visit kernel with all 22 moments ("ev_general", rdc_tet4_ev.h GEN)
+  if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.ev_general && a.use_ev && a.ev.n_wg > 0 && a.strategy == RDC_SCATTER_ROWGATHER) return launch_tet4_ev(a, k);
   if (a.nen == 4 && a.variant != RDC_VARIANT_GENERIC && a.opt_special && PihnaNoCellTransport::applies(p)) {
     // default: one thread per element visit, moments accumulated per node block (rdc_tet4_ev.hip)
     if (a.use_ev && a.ev.n_wg > 0 && a.strategy == RDC_SCATTER_ROWGATHER) return launch_tet4_ev(a, k);
@@ -466,7 +469,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   // element-visit kernel: default for the shipped-pattern PIHNA / TET4 ("kernel" = 0 or 7); the diagnostic knobs of the
   // pair kernels (ablate, stamps, slim, coefficient form, occupancy 1) and "kernel" = 5 select k_tet4_rg5 instead
   a.use_ev = c->prep_ev.ok && (c->opt_kernel == 0 || c->opt_kernel == 7) && c->opt_moments && !c->opt_slim && (!c->opt_ablate || c->opt_kernel == 7) &&
-             !c->stamps.p && c->opt_occ != 1 && c->opt_ldspad == 0;
+             (!c->stamps.p || (c->opt_kernel == 7 && c->opt_ablate == 4)) && c->opt_occ != 1 && c->opt_ldspad == 0;
   a.opt_ev_occ = c->opt_ev_occ;
   a.opt_evc_occ = c->opt_evc_occ;
   a.opt_ev_persist = c->opt_ev_persist;
@@ -493,9 +496,10 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
     hex_cl = c->solid_cl_state == 1;
   }
   bool pattern_ok = evc_model;
-  if constexpr (std::is_same<M, Pihna>::value) pattern_ok = pihna_pattern_applies(p);
+  if constexpr (std::is_same<M, Pihna>::value) pattern_ok = pihna_pattern_applies(p) || c->opt_ev_general;
   const bool ev_path = a.use_ev && (std::is_same<M, Pihna>::value || evc_model) && a.nen == 4 && a.variant != RDC_VARIANT_GENERIC &&
-                       (c->opt_special || !std::is_same<M, Pihna>::value) && a.strategy == RDC_SCATTER_ROWGATHER && pattern_ok;
+                       (c->opt_special || c->opt_ev_general || !std::is_same<M, Pihna>::value) && a.strategy == RDC_SCATTER_ROWGATHER && pattern_ok;
+  if constexpr (std::is_same<M, Pihna>::value) a.ev_general = ev_path && c->opt_ev_general && !(c->opt_special && pihna_pattern_applies(p));
   if (!std::is_same<M, Pihna>::value) a.use_ev = ev_path && c->opt_kernel == 0;   // k_tet4_evc (rdc_tet4_fast.hip dispatches on it)
   if (c->opt_part != 0 && ev_path) {
     // two-part assembly on the element-visit lists: the clusters all of whose nodes are interior run in part 1
@@ -724,7 +728,8 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     c->opt_solid_cl_waves = value;
   }
   else if (!std::strcmp(key, "ev_persistent")) c->opt_ev_persist = value ? 1 : 0;   // element-visit kernel walking over the clusters (loader wave + compute waves)
-  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value ? 1 : 0;   // element-visit kernel as three resident workgroups per CU (k_tet4_evl)
+  else if (!std::strcmp(key, "ev_general")) c->opt_ev_general = value ? 1 : 0;   // general-parameter PIHNA / TET4: element-visit kernel with 22 moments (1, default) or the pair kernel (0)
+  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value == 2 ? 2 : (value ? 1 : 0);   // element-visit kernel as three resident workgroups per CU (k_tet4_evl)
   else if (!std::strcmp(key, "evc_occupancy")) c->opt_evc_occ = value == 3 ? 3 : 2;   // k_tet4_evc: waves per SIMD its registers are bounded for
   else if (!std::strcmp(key, "ev_occupancy")) c->opt_ev_occ = value;   // element-visit kernel: 3 (default, 168 registers) or 2
   else if (!std::strcmp(key, "ev_lds")) c->opt_ev_lds = value;   // LDS bytes per workgroup the element-visit clusters are sized for (next rdc_mesh_upload)
@@ -1416,7 +1421,9 @@ int rdc_debug_stamps(rdc_ctx* c, long long* host_out, int64_t capacity, int64_t*
   if (!c->have_mesh || !c->prep.rg2_ok) return fail(c, RDC_ERR_STATE, "no row-gather work lists");
   int rc = set_device(c);
   if (rc) return rc;
-  const int64_t n = (int64_t)c->prep.wg2.size() * 4 * 9;
+  // "kernel" = 7 with "ablate" = 4: the stamped build of the element-visit kernel, [cluster][wave][12] (rdc_tet4_ev.hip, tools/ev_timeline.py)
+  const bool ev_tl = c->opt_kernel == 7 && c->opt_ablate == 4 && c->prep_ev.ok;
+  const int64_t n = ev_tl ? (int64_t)c->prep_ev.desc.size() * 4 * 12 : (int64_t)c->prep.wg2.size() * 4 * 9;
   if (!host_out) {  // arm: the next PIHNA (shipped-parameter) assembly runs the stamped diagnostic kernel
     if ((rc = dev_alloc(c, c->stamps, (size_t)n * sizeof(long long)))) return rc;
     RDC_HIP(c, hipMemsetAsync(c->stamps.p, 0, (size_t)n * sizeof(long long), c->stream));

@@ -127,6 +127,7 @@ struct PihnaK {  // src/pihna.C:358-381
   double sec_c, sec_h, upt, dec;
   // time-step-weighted rates of the moment form (rdc_tet4_pihna_moments.h): DT2 * rate, formed once on the host
   double Tn_c, Tn_h, Tn_v, Th2n, Tprod_c, Tc2h, Th2c, Tprod_v, Tdif_v, Tsec_c, Tsec_h, Tupt, Tdec;
+  double Tdif_c, Ttax_c, Tdif_h, Ttax_h, Ttax_v;   // cell transport (general-parameter moment kernel)
 };
 
 struct Pihna {
@@ -177,6 +178,7 @@ struct Pihna {
     k.Tprod_c = k.DT2 * k.prod_c; k.Tc2h = k.DT2 * k.c2h; k.Th2c = k.DT2 * k.h2c; k.Tprod_v = k.DT2 * k.prod_v;
     k.Tdif_v = k.DT2 * k.dif_v; k.Tsec_c = k.DT2 * k.sec_c; k.Tsec_h = k.DT2 * k.sec_h; k.Tupt = k.DT2 * k.upt;
     k.Tdec = k.DT2 * k.dec;
+    k.Tdif_c = k.DT2 * k.dif_c; k.Ttax_c = k.DT2 * k.tax_c; k.Tdif_h = k.DT2 * k.dif_h; k.Ttax_h = k.DT2 * k.tax_h; k.Ttax_v = k.DT2 * k.tax_v;
     return k;
   }
   static inline double exponent(const K& k) { return k.ek; }

@@ -98,6 +98,7 @@ struct LaunchArgs {
   int opt_ev_occ = 3;
   int opt_evc_occ = 2;
   int opt_ev_persist = 0, ev_grid = 0;   // persistent form of the element-visit kernel (k_tet4_evp) and its grid (workgroups resident at once)
+  bool ev_general = false;   // k_tet4_ev with every PIHNA term on (22 moments) instead of the shipped parameter pattern (16)
   int opt_ev_resident = 0;   // k_tet4_evl: three resident workgroups per CU walking over the clusters (experimental)
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;
@@ -126,6 +127,7 @@ hipError_t launch_tet4_evc(const LaunchArgs& a, const typename M::K& k);
 // which models run it: measured on K(94) against k_tet4_rg5 (tools/ab.py): Ripf with all terms on 1.41 vs 1.79 ms (the per-element
 // part -- two exp, sqrt, the unit gradient -- dominates); RipfReduced 0.87 vs 0.78, Hcc 0.90 vs 0.65: the pair kernel packs the
 // row atomics of a wave densely, an element visit executes a row position for as few as 10 of 64 lanes
+// (Pihna with all terms on, five unknowns, was tried in round 3: tet4_visit<Pihna> needs 3.9 KB of scratch per lane -- profiles/r03_ev_ab_log.md)
 template <class M> struct EvcEligible { static constexpr bool value = std::is_same<M, Ripf>::value; };
 
 }  // namespace rdc

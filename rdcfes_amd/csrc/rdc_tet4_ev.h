@@ -25,11 +25,15 @@
 namespace rdc {
 namespace ev {
 
-constexpr int NM = 16;    // moments per node block
+constexpr int NM = 16;    // moments per node block (shipped parameter pattern: cell transport off)
+constexpr int NMG = 22;   // ... with every term on (the six transport moments of the c and h rows behind the 16)
 constexpr int NBP = 256;  // node blocks per workgroup (padded): moment m of block b lives at M[m * NBP + b]
 constexpr int MAXN = 16;  // owned nodes per workgroup
-enum { M_E1, M_EoV, M_EPh, M_EQh, M_En, M_Ec, M_Eh, M_Ev, M_Ea, M_Ex, M_Ey, M_ETau, M_EdTc, M_Epv, M_Eg4, M_Edd };
+enum { M_E1, M_EoV, M_EPh, M_EQh, M_En, M_Ec, M_Eh, M_Ev, M_Ea, M_Ex, M_Ey, M_ETau, M_EdTc, M_Epv, M_Eg4, M_Edd,
+       M_Xc, M_Yc, M_Zc, M_Xh, M_Yh, M_Zh };
 constexpr bool symmetric_moment(int m) { return m != M_Epv; }   // E_m(i, j) == E_m(j, i)
+// general parameters: the taxis parts gk_i F_j are not symmetric; M_Edd then also carries the taxis part of block (v, v)
+constexpr bool symmetric_moment_gen(int m) { return m != M_Epv && m != M_Edd && m != M_Xc && m != M_Yc && m != M_Xh && m != M_Yh; }
 
 // One element visit.  X, U: the element's vertices with the `r` cluster-owned ones first (any vertex order is legal:
 // grad phi = cofactor / det and every product used here is invariant under the orientation).
@@ -38,7 +42,14 @@ constexpr bool symmetric_moment(int m) { return m != M_Epv; }   // E_m(i, j) == 
 // contribution is only added to block (j -> i) by row j, and the expansion adds the moments of the MIRROR block
 // (column node -> row node, HostPrepEv::bpart) to a block's own.  Row position i then issues 15 (4 - i) + 4 + 5 atomics
 // instead of 69 -- the under-filled high row positions of a wave are the cheap ones.
-template <int EXP_MODE, class Sink, bool MIRROR = true>
+// GEN: every term of Pihna::coef() (diffuse/c, taxis/c, diffuse/h, taxis/h, taxis/v != 0): with the gradient projections
+// gk_i[f] = grad f . grad phi_i, dd_ij = grad phi_i . grad phi_j and the first moments F_j(beta) = sum_q JxW_q beta(q) phi_j(q)
+//   X_c(i,j) = gk_i[c] F_j(T dif_c dT) + gk_i[v] F_j(T tax_c dT c)          -> blocks (c, n..v)   (coef: B[1][b][0], B[1][b][2])
+//   Y_c(i,j) = gk_i[v] F_j(T tax_c Tau) + dd_ij sum_q JxW_q T dif_c Tau     -> block (c, c)       (B[1][1][2] extra, D[1][1])
+//   Z_c(i,j) = dd_ij sum_q JxW_q T tax_c Tau c                              -> block (c, v)       (D[1][3])
+// (transport coefficients thresholded per point, src/pihna.C:504-509), the same for h, and for taxis/v: B[3][b][3] joins M_Epv,
+// the extra of B[3][3][3] joins M_Edd (both feed block (v, v) only), D[3][4] joins M_Eg4 (block (v, a)).
+template <int EXP_MODE, class Sink, bool MIRROR = true, bool GEN = false>
 RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (&U)[4][5], const int r, Sink& sink) {
   // ---- geometry: unscaled cofactors g_j = det * grad phi_j ------------------------------------------------------
   double e1[3], e2[3], e3[3];
@@ -133,19 +144,100 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
 #pragma unroll
     for (int d = 0; d < 3; d++) gv[d] = (U[0][3] * g[0][d] + U[1][3] * g[1][d]) + (U[2][3] * g[2][d] + U[3][3] * g[3][d]);
     const double sTi = sT * inv2, Td2 = k.Tdif_v * inv2;
+    // taxis/v (GEN): gradient of a; F(tax_v dT v) joins pv, F(tax_v Tau) joins block (v, v), sum tax_v Tau v joins (v, a) and the rhs
+    double ga[3] = {0.0, 0.0, 0.0}, FSa = 0.0, fa_[4] = {0.0, 0.0, 0.0, 0.0}, FSy = 0.0, fy_[4] = {0.0, 0.0, 0.0, 0.0}, sZv = 0.0;
+    if (GEN) {
+#pragma unroll
+      for (int d = 0; d < 3; d++) ga[d] = (U[0][4] * g[0][d] + U[1][4] * g[1][d]) + (U[2][4] * g[2][d] + U[3][4] * g[3][d]);
+      const double Tt = k.Ttax_v * inv2;
+      {
+        RDC_EV_PT(b, s[q].v > k.Lambda ? s[q].dT * s[q].v : 0.0)
+        FSa = Tt * (Wc * 0.25 * b[0] + Wh * (1.0 / 6.0) * ((b[1] + b[2]) + (b[3] + b[4])));
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa_[j] = Tt * (Wh * (1.0 / 3.0)) * b[j + 1];
+      }
+      {
+        RDC_EV_PT(b, s[q].v > k.Lambda ? s[q].Tau : 0.0)
+        FSy = Tt * (Wc * 0.25 * b[0] + Wh * (1.0 / 6.0) * ((b[1] + b[2]) + (b[3] + b[4])));
+#pragma unroll
+        for (int j = 0; j < 4; j++) fy_[j] = Tt * (Wh * (1.0 / 3.0)) * b[j + 1];
+      }
+      {
+        RDC_EV_PT(b, s[q].v > k.Lambda ? s[q].Tau * s[q].v : 0.0)
+        sZv = Tt * (Wc * b[0] + Wh * ((b[1] + b[2]) + (b[3] + b[4])));
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) if (i < r) {
       const double gki = gv[0] * g[i][0] + gv[1] * g[i][1] + gv[2] * g[i][2];   // unscaled
       const double gkT = Td2 * gki;                                               // Tdif_v * grad v . grad phi_i
-      const double rb_ = Sm_ + t_[i] + gkT * FS;
+      const double gai = GEN ? ga[0] * g[i][0] + ga[1] * g[i][1] + ga[2] * g[i][2] : 0.0;   // unscaled (the factor 1 / det^2 is in FSa, fa_, FSy, fy_, sZv)
+      double rb_ = Sm_ + t_[i] + gkT * FS;
+      if (GEN) rb_ += gai * FSa;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        // pv(i,j) = Tdif_v gk_i F(dT_on)(j) - Tprod_v E(dT Ua v)(i,j)        (coef: B[3][b][2] and -T pv)
-        sink.mom(M_Epv, i, j, (j == i ? rb_ + 3.0 * t_[i] : rb_ + t_[j]) + gkT * f_[j]);
-        // dd(i,j) * Tdif_v * sum_q JxW_q Tau_on(q)                            (coef: D[3][3])
-        if (!MIRROR || j >= i) sink.mom(M_Edd, i, j, sTi * (g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2]));
+        // pv(i,j) = Tdif_v gk_i F(dT_on)(j) - Tprod_v E(dT Ua v)(i,j)        (coef: B[3][b][2] and -T pv)  [+ Ttax_v gk_i[a] F(dT v)(j): B[3][b][3]]
+        double pv_ = (j == i ? rb_ + 3.0 * t_[i] : rb_ + t_[j]) + gkT * f_[j];
+        if (GEN) pv_ += gai * fa_[j];
+        sink.mom(M_Epv, i, j, pv_);
+        // dd(i,j) * Tdif_v * sum_q JxW_q Tau_on(q)                            (coef: D[3][3])  [+ Ttax_v gk_i[a] F(Tau)(j): the extra of B[3][3][3]]
+        const double dd_ = g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2];
+        if (GEN) {
+          sink.mom(M_Edd, i, j, sTi * dd_ + gai * (FSy + fy_[j]));
+          if (!MIRROR || j >= i) sink.mom(M_Eg4, i, j, sZv * dd_);              // D[3][4]: block (v, a), on top of M_Eg4's own part below
+        } else if (!MIRROR || j >= i) sink.mom(M_Edd, i, j, sTi * dd_);
       }
-      sink.rhs(3, i, -(sTi * gki));                                               // RG[3][2]: -dcoef * gk_i
+      sink.rhs(3, i, GEN ? -(sTi * gki + sZv * gai) : -(sTi * gki));              // RG[3][2] (, RG[3][3]): -dcoef * gk_i
+    }
+  }
+  // ---- cell transport (GEN): rows c (species 1) and h (species 2), gradient fields (own, v) ---------------------------------
+  if (GEN) {
+#pragma unroll
+    for (int sp = 1; sp <= 2; sp++) {
+      const double Tdif = sp == 1 ? k.Tdif_c : k.Tdif_h, Ttax = sp == 1 ? k.Ttax_c : k.Ttax_h;
+      if (Tdif == 0.0 && Ttax == 0.0) continue;   // uniform
+      double go[3], gv[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        go[d] = (U[0][sp] * g[0][d] + U[1][sp] * g[1][d]) + (U[2][sp] * g[2][d] + U[3][sp] * g[3][d]);
+        gv[d] = (U[0][3] * g[0][d] + U[1][3] * g[1][d]) + (U[2][3] * g[2][d] + U[3][3] * g[3][d]);
+      }
+      // first moments (FS + f_j) of the thresholded point functions, zero-order sums; all carry 1 / det^2 for the unscaled projections
+      double FS1, f1[4], FS2, f2[4], FS3, f3[4], sD, sZ;
+      const double Td = Tdif * inv2, Tt = Ttax * inv2;
+#define RDC_EV_F(FSx, fx, scale, expr)                                                                     \
+      {                                                                                                     \
+        RDC_EV_PT(b, ((sp == 1 ? s[q].c : s[q].h) > k.Lambda) ? (expr) : 0.0)                             \
+        FSx = (scale) * (Wc * 0.25 * b[0] + Wh * (1.0 / 6.0) * ((b[1] + b[2]) + (b[3] + b[4])));         \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) fx[j] = (scale) * (Wh * (1.0 / 3.0)) * b[j + 1];   \
+      }
+      RDC_EV_F(FS1, f1, Td, s[q].dT)
+      RDC_EV_F(FS2, f2, Tt, s[q].dT * (sp == 1 ? s[q].c : s[q].h))
+      RDC_EV_F(FS3, f3, Tt, s[q].Tau)
+#undef RDC_EV_F
+      {
+        RDC_EV_PT(b, ((sp == 1 ? s[q].c : s[q].h) > k.Lambda) ? s[q].Tau : 0.0)
+        sD = Td * (Wc * b[0] + Wh * ((b[1] + b[2]) + (b[3] + b[4])));
+      }
+      {
+        RDC_EV_PT(b, ((sp == 1 ? s[q].c : s[q].h) > k.Lambda) ? s[q].Tau * (sp == 1 ? s[q].c : s[q].h) : 0.0)
+        sZ = Tt * (Wc * b[0] + Wh * ((b[1] + b[2]) + (b[3] + b[4])));
+      }
+      const int mX = sp == 1 ? M_Xc : M_Xh, mY = sp == 1 ? M_Yc : M_Yh, mZ = sp == 1 ? M_Zc : M_Zh;
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i < r) {
+        const double gko = go[0] * g[i][0] + go[1] * g[i][1] + go[2] * g[i][2];   // unscaled projections
+        const double gkv = gv[0] * g[i][0] + gv[1] * g[i][1] + gv[2] * g[i][2];
+        const double xb = gko * FS1 + gkv * FS2, yb = gkv * FS3;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const double dd_ = g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2];
+          sink.mom(mX, i, j, xb + gko * f1[j] + gkv * f2[j]);
+          sink.mom(mY, i, j, yb + gkv * f3[j] + sD * dd_);
+          if (!MIRROR || j >= i) sink.mom(mZ, i, j, sZ * dd_);
+        }
+        sink.rhs(sp, i, -(sD * gko + sZ * gkv));                                  // RG[sp][own], RG[sp][2]
+      }
     }
   }
   // ---- vascular-fraction functions (coef: oneVe, nVe_dc = Ve rV =: P, Ve_dv = oneVe rV =: Q) ----------------------
@@ -193,7 +285,9 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
   { RDC_EV_PT(b, s[q].c) RDC_EV_SYM(M_Ec, b) }
   { RDC_EV_PT(b, s[q].h) RDC_EV_SYM(M_Eh, b) }
   { RDC_EV_PT(b, s[q].v) RDC_EV_SYM(M_Ev, b) }
-  { RDC_EV_PT(b, s[q].a) RDC_EV_SYM(M_Ea, b) }
+  // E(a) only enters through the uptake rate (pihna_expand: o[23] = Tupt E(a)): with uptake/a/from/v = 0, the shipped value, its ten
+  // atomics per visit are not issued (k is uniform: a scalar branch); the slice keeps its zeros and o[23] = 0 * 0
+  if (k.Tupt != 0.0) { RDC_EV_PT(b, s[q].a) RDC_EV_SYM(M_Ea, b) }
   { RDC_EV_PT(b, s[q].Tau) RDC_EV_SYM(M_ETau, b) }
   { RDC_EV_PT(b, s[q].dT * s[q].c) RDC_EV_SYM(M_EdTc, b) }
 #undef RDC_EV_SYM
@@ -202,7 +296,8 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
 
 // The 25 entries of a node block from its 16 moments (e[m]); o[a * 5 + b].  Same formulas as the rows of
 // rdc_tet4_pihna_moments.h (coef: A[a][b] with the factor -T, the mass term on the diagonal blocks).
-RDC_HD void pihna_expand(const PihnaK& k, const double (&e)[NM], double (&o)[25]) {
+template <int NMT>
+RDC_HD void pihna_expand(const PihnaK& k, const double (&e)[NMT], double (&o)[25]) {
   const double E1 = e[M_E1], EoV = e[M_EoV], EPh = e[M_EPh], EQh = e[M_EQh], En = e[M_En], Ec = e[M_Ec], Eh = e[M_Eh], Ev = e[M_Ev];
   const double x = e[M_Ex], y = e[M_Ey], pcj = k.Tprod_c * e[M_EdTc], pv = e[M_Epv];
   // n equation
@@ -236,6 +331,11 @@ RDC_HD void pihna_expand(const PihnaK& k, const double (&e)[NM], double (&o)[25]
   o[22] = -(k.Tsec_h * E1);
   o[23] = k.Tupt * e[M_Ea];
   o[24] = E1 + k.Tupt * Ev + k.Tdec * E1;
+  if (NMT == NMG) {   // cell transport: rdc_tet4_ev.h, GEN
+    const double Xc = e[M_Xc % NMT], Xh = e[M_Xh % NMT];
+    o[5] += Xc; o[6] += Xc + e[M_Yc % NMT]; o[7] += Xc; o[8] += Xc + e[M_Zc % NMT];
+    o[10] += Xh; o[11] += Xh; o[12] += Xh + e[M_Yh % NMT]; o[13] += Xh + e[M_Zh % NMT];
+  }
 }
 
 }  // namespace ev

@@ -19,9 +19,11 @@ template <class M> struct RecEv {
   static constexpr int N = (RAW + 1) & ~1;
 };
 
-// ABL (diagnostic builds, results WRONG): 1 = plain LDS stores instead of atomics, 2 = no LDS accumulation traffic
-template <int ABL>
+// ABL (diagnostic builds): 1 = plain LDS stores instead of atomics, 2 = no LDS accumulation traffic, 3 = no compute phase (results WRONG);
+// 4 = the real kernel with s_memtime stamps per wave and phase (results right; tools/ev_timeline.py)
+template <int ABL_>
 struct EvSink {
+  static constexpr int ABL = ABL_ == 4 ? 0 : ABL_;
   double* p[4][4];   // LDS address of moment 0 of block (node i, node j)
   double* pr[4];     // LDS address of rhs entry 0 of node i
   double sum = 0.0;
@@ -38,14 +40,20 @@ struct EvSink {
 };
 
 
-template <int EXP_MODE, int MINW, int ABL = 0>
+// GEN: every term on (22 moments, rdc_tet4_ev.h); otherwise the shipped parameter pattern (16)
+template <int EXP_MODE, int MINW, int ABL = 0, bool GEN = false>
 __global__ void __launch_bounds__(256, MINW)
 k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
-          double* __restrict__ rhs, const int nls, const int wg_begin, const int xcd_n, const int stagger) {
+          double* __restrict__ rhs, const int nls, const int wg_begin, const int xcd_n, const int stagger,
+          long long* __restrict__ stamps) {
   constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
-  constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
+  constexpr bool TL = ABL == 4;
+  long long ts[11];
+#define RDC_TS(x) if (TL) ts[x] = __builtin_amdgcn_s_memtime()
+  RDC_TS(0);
+  constexpr int NM = GEN ? ev::NMG : ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP | R: 5 x MAXN | records: NP x nls x 16 B]
   __shared__ HostPrepEv::Node snode[MAXN];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -77,16 +85,17 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
   // register (address = M0 + offset + 4 * lane), so zeroing the 32 KB slice costs 2 cycles per 256 bytes instead of 13 per
   // 1024 with 16-byte stores.  Wave wv clears its quarter of the slice; M0 is restored (the LDS-DMA below sets it too).
   {
-    static_assert(NM * NBP * 8 == 4 * 32 * 256, "zeroing: 4 waves x 32 addtid stores of 256 bytes");
-    const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)__builtin_amdgcn_readfirstlane(wv) * 8192u;
+    static_assert((NM * NBP * 8) % (4 * 1024) == 0, "zeroing: 4 waves x (NM / 2) groups of four addtid stores of 256 bytes");
+    constexpr int PER_WAVE = NM * NBP * 8 / 4;   // bytes
+    const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)__builtin_amdgcn_readfirstlane(wv) * (uint32_t)PER_WAVE;
     const uint32_t zero = 0u;
     uint32_t m0_saved;
-#define RDC_Z4(o) "ds_write_addtid_b32 %1 offset:" #o "\n\tds_write_addtid_b32 %1 offset:" #o "+256\n\tds_write_addtid_b32 %1 offset:" #o "+512\n\tds_write_addtid_b32 %1 offset:" #o "+768\n\t"
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 RDC_Z4(0) RDC_Z4(1024) RDC_Z4(2048) RDC_Z4(3072) RDC_Z4(4096) RDC_Z4(5120) RDC_Z4(6144) RDC_Z4(7168)
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(m0_saved) : "v"(zero), "s"(zbase) : "memory");
-#undef RDC_Z4
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0" : "=&s"(m0_saved) : "s"(zbase) : "memory");
+#pragma unroll
+    for (int o = 0; o < PER_WAVE; o += 1024)
+      asm volatile("ds_write_addtid_b32 %0 offset:%1\n\tds_write_addtid_b32 %0 offset:%1+256\n\tds_write_addtid_b32 %0 offset:%1+512\n\tds_write_addtid_b32 %0 offset:%1+768"
+                   :: "v"(zero), "n"(o) : "memory");
+    asm volatile("s_mov_b32 m0, %0" :: "s"(m0_saved) : "memory");
     if (tid < 5 * MAXN) lds[NM * NBP + tid] = 0.0;
   }
   const int rounds = nls >> 6;
@@ -103,8 +112,11 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
     for (int p = 0; p < NP; p++)
       __builtin_amdgcn_global_load_lds((glb_ptr)(src + p * 16), (lds_ptr)(recs + (p * nls + wv * 64) * 2), 16, 0, 0);
   }
+  RDC_TS(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RDC_TS(2);
   __syncthreads();
+  RDC_TS(3);
   // phase 1: element visits
   if (pl != 0xFFFFFFFFu) {
     double X[4][3], U[4][5];
@@ -134,10 +146,13 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);   // block (a, slot): slot * 16 + a
     }
-    if (ABL < 3) ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);   // ABL 3: no compute phase at all (data movement only)
+    if (ABL != 3) ev::pihna_visit<EXP_MODE, EvSink<ABL>, true, GEN>(k, X, U, r, sink);   // ABL 3: no compute phase at all (data movement only)
     if (ABL == 2 && sink.sum == 1.2345e300) rhs[0] = sink.sum;  // keeps the arithmetic alive
   }
+  if (TL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS atomics have been executed
+  RDC_TS(4);
   __syncthreads();
+  RDC_TS(5);
   // phase 2: node block tid = slot * 16 + node: moments -> entries
   double e[NM];
   const int bn = tid & (MAXN - 1), bs = tid >> 4;
@@ -148,13 +163,14 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
     if (mirror != tid) {   // rdc_tet4_ev.h, MIRROR
 #pragma unroll
       for (int m = 0; m < NM; m++)
-        if (ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
+        if (GEN ? ev::symmetric_moment_gen(m) : ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
     }
   }
   if (tid < (int)d.nown * 5) {   // rhs: R[a][node] -> rhs[node * 5 + a]
     const int n = tid / 5, a = tid - n * 5;
     rhs[(size_t)snode[n].node * 5 + a] = R[a * MAXN + n];
   }
+  RDC_TS(6);
   __syncthreads();   // every moment has been read: the image may overwrite the slice
   if (has) {
     double o[25];
@@ -167,7 +183,9 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
 #pragma unroll
       for (int b = 0; b < 5; b++) dst[a * len5 + b] = o[a * 5 + b];
   }
+  RDC_TS(7);
   __syncthreads();
+  RDC_TS(8);
   // phase 3: one contiguous CSR segment per node; the image has the 16-byte phase of its segment in memory
   for (int n = wv; n < (int)d.nown; n += 4) {
     const HostPrepEv::Node nd = snode[n];
@@ -183,6 +201,19 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
     if (sh && lane == 0) __builtin_nontemporal_store(img[0], out);
     if (((cnt - sh) & 1) && lane == 1) __builtin_nontemporal_store(img[cnt - 1], out + cnt - 1);
   }
+  if (TL) {
+    RDC_TS(9);
+    if (stagger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's stores have been acknowledged ("stagger" != 0: not waited for)
+    RDC_TS(10);
+    if (lane == 0 && stamps) {
+      long long* o = stamps + ((int64_t)blockIdx.x * 4 + wv) * 12;
+#pragma unroll
+      for (int x = 0; x < 11; x++) o[x] = ts[x];
+      // HW_REG_HW_ID (4): wave 3:0, simd 5:4, cu 11:8, sh 12, se 15:13;  HW_REG_XCC_ID (20): xcc 3:0
+      o[11] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+  }
+#undef RDC_TS
 }
 
 
@@ -340,6 +371,215 @@ k_tet4_evl(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     lds_barrier();   // the image and the node table have been read (into the stores' registers): the next cluster may land
     nid = nid_next;
   }
+}
+
+// ---- pipelined resident form ("ev_resident" = 2, experimental) -------------------------------------------------------------------
+// The stamped build of k_tet4_ev (tools/ev_timeline.py, K(119)) puts 23 % of a workgroup's life into phase 0 -- list loads, the
+// dependent record DMA, the barrier behind the slowest wave's loads -- during which its LDS and registers do nothing; the
+// stores are not what it waits for at its end (1 %).  Here three workgroups per CU stay resident (as k_tet4_evl) and fetch
+// cluster i + 1 WHILE cluster i is expanded and copied out: behind the barrier that ends the visits of cluster i every wave
+// issues the LDS-DMA of the records and lists of cluster i + 1 (node ids DMA'd one cluster earlier) and of the node ids of
+// cluster i + 2.  They land during the moment reads, the expansion and the copy-out; the one s_waitcnt vmcnt(0) at the top of a
+// cluster then only waits for the copy-out stores just issued.  Everything is fetched by LDS-DMA in asm the compiler does not
+// see (no result registers, no compiler-placed vmcnt waits), and nothing between the fetch and the top of the next cluster may
+// touch scratch (a scratch reload waits for every earlier vector-memory operation of its wave).
+// LDS: the record and list landing areas may not be covered by the CSR image, so the image is built and sent in two halves
+// (nodes 0-7 by waves 0-1, nodes 8-15 by waves 2-3: at most 8 x 16 x 25 doubles, inside the 32 KB moment slice); 46 KB per workgroup.
+namespace {
+struct EvqLists {   // landing area of a cluster's lists (bytes): visit positions, column slots, then mirror blocks | node table | descriptor; node ids x 2
+  static constexpr int PL = 0, SL = 1024, MISC = SL + 2048, MIRROR = MISC, SNODE = MISC + 256, DESC = MISC + 512, NL = MISC + 544;
+  static constexpr int bytes(int nls) { return NL + 2 * nls * 4; }
+};
+}
+template <int EXP_MODE, bool TL>
+__global__ void __launch_bounds__(256, 3)
+k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
+           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
+           const PihnaK k, const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int nls,
+           const int wg_begin, const int wg_count, long long* __restrict__ stamps) {
+  constexpr int BLOCK = 256, NP = 4;
+  constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP, later the image halves | R: 5 x MAXN | records: NP x nls x 16 B | lists]
+  __shared__ HostPrepEv::Node snode[MAXN];
+  __shared__ uint8_t smirror[NBP];
+  __shared__ int s_nown;
+  double* const R = lds + NM * NBP;
+  double* const recs = R + 5 * MAXN;
+  char* const lists = reinterpret_cast<char*>(recs + (size_t)NP * nls * 2);
+  const int rounds = nls >> 6;
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int n_it = (wg_count - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid is <= wg_count
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  long long ts[8];
+#define RDC_TS(x) if (TL) ts[x] = __builtin_amdgcn_s_memtime()
+  // everything cluster `w` needs (node ids in `nid`), and the node ids of cluster `w2` into id buffer `nb2`, by LDS-DMA
+  auto fetch = [&](const int w, const uint32_t nid, const int w2, const int nb2, const int lane) {
+    if (wv < rounds) {
+      const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
+#pragma unroll
+      for (int p = 0; p < NP; p++) evl_dma16(src + p * 16, recs + (p * nls + wv * 64) * 2);
+    }
+    if (wv == 0) evl_dma16(reinterpret_cast<const char*>(vloc + (size_t)w * BLOCK) + lane * 16, lists + EvqLists::PL);
+    else if (wv < 3) evl_dma16(reinterpret_cast<const char*>(vslot + (size_t)w * BLOCK * 2) + (wv - 1) * 1024 + lane * 16, lists + EvqLists::SL + (wv - 1) * 1024);
+    else {
+      if (lane < 34) {
+        const char* src = lane < 16 ? reinterpret_cast<const char*>(bpart + (size_t)w * NBP) + lane * 16
+                        : lane < 32 ? reinterpret_cast<const char*>(ntab + (size_t)w * MAXN) + (lane - 16) * 16
+                                    : reinterpret_cast<const char*>(desc + w) + (lane - 32) * 16;
+        evl_dma16(src, lists + EvqLists::MISC);
+      }
+      if (w2 >= 0 && lane < (nls >> 2)) evl_dma16(reinterpret_cast<const char*>(nlist + (size_t)w2 * nls) + lane * 16, lists + EvqLists::NL + nb2 * nls * 4);
+    }
+  };
+  {
+    const int w0 = wg_begin + (int)blockIdx.x;
+    uint32_t nid0 = 0;
+    if (wv < rounds) nid0 = nlist[(size_t)w0 * nls + threadIdx.x];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nid0)::"memory");
+    fetch(w0, nid0, n_it > 1 ? w0 + (int)gridDim.x : -1, 1, (int)(threadIdx.x & 63));
+  }
+#pragma unroll 1
+  for (int it = 0; it < n_it; it++) {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));   // recomputed every iteration (k_tet4_evl)
+    const int w = wg_begin + (int)blockIdx.x + it * (int)gridDim.x;
+    RDC_TS(0);
+    {   // zero [M | R] (ds_write_addtid_b32: k_tet4_ev); the image of the previous cluster has been read (barrier at its end)
+      const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)wv * 8192u;
+      const uint32_t zero = 0u;
+      uint32_t m0_saved;
+#define RDC_Z4(o) "ds_write_addtid_b32 %1 offset:" #o "\n\tds_write_addtid_b32 %1 offset:" #o "+256\n\tds_write_addtid_b32 %1 offset:" #o "+512\n\tds_write_addtid_b32 %1 offset:" #o "+768\n\t"
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   RDC_Z4(0) RDC_Z4(1024) RDC_Z4(2048) RDC_Z4(3072) RDC_Z4(4096) RDC_Z4(5120) RDC_Z4(6144) RDC_Z4(7168)
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "v"(zero), "s"(zbase) : "memory");
+#undef RDC_Z4
+      if (wv * 64 + lane < 5 * MAXN) lds[NM * NBP + wv * 64 + lane] = 0.0;
+    }
+    // the one wait of the cluster: what was fetched for it while the previous one was expanded -- and that one's stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RDC_TS(1);
+    lds_barrier();
+    RDC_TS(2);
+    {
+      const int tid = wv * 64 + lane;
+      const uint32_t pl = *reinterpret_cast<const uint32_t*>(lists + EvqLists::PL + tid * 4);
+      const uint2 sl = *reinterpret_cast<const uint2*>(lists + EvqLists::SL + tid * 8);
+      const int nown = (int)reinterpret_cast<const HostPrepEv::Desc*>(lists + EvqLists::DESC)->nown;
+      // what the expansion needs from the lists is parked where the next fetch does not land
+      {
+        const int blk = (((wv & 1) << 3) | (lane >> 3)) * MAXN + (((wv >> 1) << 3) | (lane & 7));
+        smirror[blk] = *reinterpret_cast<const uint8_t*>(lists + EvqLists::MIRROR + blk);
+        if (tid < MAXN) snode[tid] = *reinterpret_cast<const HostPrepEv::Node*>(lists + EvqLists::SNODE + tid * 16);
+        if (tid == 0) s_nown = nown;
+      }
+      // ---- element visits (phase 1 of k_tet4_ev)
+      if (pl != 0xFFFFFFFFu) {
+        double X[4][3], U[4][5];
+        int li[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          li[j] = (pl >> (8 * j)) & 0xFF;
+          double rr[2 * NP];
+#pragma unroll
+          for (int p = 0; p < NP; p++) {
+            const double2 v2 = reinterpret_cast<const double2*>(recs)[p * nls + li[j]];
+            rr[2 * p] = v2.x; rr[2 * p + 1] = v2.y;
+          }
+          X[j][0] = rr[0]; X[j][1] = rr[1]; X[j][2] = rr[2];
+#pragma unroll
+          for (int v = 0; v < 5; v++) U[j][v] = rr[3 + v];
+        }
+        const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
+        EvSink<0> sink;
+        const uint32_t sw[4] = {sl.x & 0xFFFFu, sl.x >> 16, sl.y & 0xFFFFu, sl.y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int a = (i < r) ? li[i] : 0;
+          sink.pr[i] = R + a;
+#pragma unroll
+          for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);
+        }
+        ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
+      }
+    }
+    RDC_TS(3);
+    lds_barrier();   // every visit has read its lists and records and added its moments
+    RDC_TS(4);
+    // ---- from here to the top of the next cluster: NO scratch (the lane index is taken from the hardware again)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    if (it + 1 < n_it) {
+      uint32_t nid = 0;
+      if (wv < rounds) nid = *reinterpret_cast<const uint32_t*>(lists + EvqLists::NL + (((it + 1) & 1) * nls + wv * 64 + lane) * 4);
+      fetch(w + (int)gridDim.x, nid, it + 2 < n_it ? w + 2 * (int)gridDim.x : -1, it & 1, lane);
+    }
+    // ---- node block (bn, bs): moments -> entries; waves 0-1 hold the blocks of nodes 0-7, waves 2-3 those of nodes 8-15
+    const int nown = s_nown;
+    const int bn = ((wv >> 1) << 3) | (lane & 7), bs = ((wv & 1) << 3) | (lane >> 3), blk = bs * MAXN + bn;
+    double e[NM];
+    const bool has = bn < nown && bs < (int)snode[bn < nown ? bn : 0].len;
+#pragma unroll
+    for (int m = 0; m < NM; m++) e[m] = 0.0;
+    if (has) {
+      const int mirror = (int)smirror[blk];
+#pragma unroll
+      for (int m = 0; m < NM; m++) e[m] = lds[m * NBP + blk];
+      if (mirror != blk) {
+#pragma unroll
+        for (int m = 0; m < NM; m++)
+          if (ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
+      }
+    }
+    {
+      const int tid = wv * 64 + lane;
+      if (tid < nown * 5) {
+        const int n = tid / 5, a = tid - n * 5;
+        rhs[(size_t)snode[n].node * 5 + a] = R[a * MAXN + n];
+      }
+    }
+    double o[25];
+    ev::pihna_expand(k, e, o);
+    lds_barrier();   // every moment has been read: the image halves may overwrite the slice
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int n0 = h * 8;
+      if (n0 >= nown) break;   // uniform
+      const uint32_t base = h == 0 ? 0u : (snode[8].obase & ~1u);   // even: the 16-byte phase of the segments is kept
+      if ((wv >> 1) == h && has) {
+        const int len5 = 5 * (int)snode[bn].len;
+        double* dst = lds + (snode[bn].obase - base) + 5 * bs;
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+          for (int b = 0; b < 5; b++) dst[a * len5 + b] = o[a * 5 + b];
+      }
+      lds_barrier();
+      const int n1 = nown < n0 + 8 ? nown : n0 + 8;
+      for (int n = n0 + wv; n < n1; n += 4) {
+        const HostPrepEv::Node nd = snode[n];
+        const int cnt = 25 * (int)nd.len;
+        double* out = val + (size_t)25 * nd.bptr;
+        const double* img = lds + (nd.obase - base);
+        const int sh = (int)(nd.obase & 1);
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        const int npair = (cnt - sh) >> 1;
+        const v2d_t* src = reinterpret_cast<const v2d_t*>(img + sh);
+        v2d_t* dstg = reinterpret_cast<v2d_t*>(out + sh);
+        for (int x = lane; x < npair; x += 64) __builtin_nontemporal_store(src[x], dstg + x);
+        if (sh && lane == 0) __builtin_nontemporal_store(img[0], out);
+        if (((cnt - sh) & 1) && lane == 1) __builtin_nontemporal_store(img[cnt - 1], out + cnt - 1);
+      }
+      lds_barrier();   // the half has been read (into the stores' registers)
+    }
+    RDC_TS(5);
+    if (TL && lane == 0 && stamps) {
+      long long* op = stamps + ((int64_t)(w - wg_begin) * 4 + wv) * 12;
+#pragma unroll
+      for (int x = 0; x < 6; x++) op[x] = ts[x];
+      op[11] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+  }
+#undef RDC_TS
 }
 
 // ---- persistent form ("ev_persistent" = 1) ----------------------------------------------------------------------------------
@@ -551,7 +791,7 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
   const int wg_count = E.wg_count < 0 ? E.n_wg - E.wg_begin : E.wg_count;
   if (wg_count <= 0) return hipSuccess;
-  if (a.opt_ev_persist && E.nls <= 256) {   // "ablate" = timing diagnostics of this kernel (bit mask, see its last argument)
+  if (a.opt_ev_persist && E.nls <= 256 && !a.ev_general) {   // "ablate" = timing diagnostics of this kernel (bit mask, see its last argument)
     int grid = a.ev_grid > 0 ? a.ev_grid : 512;
     if (grid > wg_count) grid = wg_count;
     const size_t accd = (size_t)ev::NM * ev::NBP + 5 * ev::MAXN;
@@ -568,10 +808,22 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
                          a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, (int)main_doubles, a.opt_ablate);
     return hipGetLastError();
   }
-  const size_t acc = (size_t)ev::NM * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
+  const size_t acc = (size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
   const size_t lds_doubles = acc > E.max_out_doubles ? acc : E.max_out_doubles;
   const size_t lds_bytes = lds_doubles * sizeof(double);
-  if (a.opt_ev_resident && !E.wg_perm && !a.opt_ablate) {   // resident workgroups walking over the clusters (whole-mesh launches only)
+  if (a.opt_ev_resident == 2 && !E.wg_perm && (!a.opt_ablate || a.opt_ablate == 4) && !a.ev_general) {   // pipelined resident workgroups (whole-mesh launches only)
+    int grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? a.ev_grid / 2 * 3 : 768);   // three per CU
+    if (grid > wg_count) grid = wg_count;
+    const size_t bytes = ((size_t)ev::NM * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2) * sizeof(double) + EvqLists::bytes(E.nls);
+#define RDC_EVQ(MODE, TLV)                                                                                                              \
+  hipLaunchKernelGGL((k_tet4_evq<MODE, TLV>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, \
+                     a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, a.stamps)
+    if (a.opt_ablate == 4) { if (a.exp_mode == 3) RDC_EVQ(3, true); else RDC_EVQ(0, true); }
+    else { if (a.exp_mode == 3) RDC_EVQ(3, false); else RDC_EVQ(0, false); }
+#undef RDC_EVQ
+    return hipGetLastError();
+  }
+  if (a.opt_ev_resident && !E.wg_perm && !a.opt_ablate && !a.ev_general) {   // resident workgroups walking over the clusters (whole-mesh launches only)
     int grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? a.ev_grid / 2 * 3 : 768);   // three per CU
     if (grid > wg_count) grid = wg_count;
     if (a.exp_mode == 3)
@@ -584,13 +836,23 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   }
 #define RDC_EV(MODE, MINW)                                                                                          \
   hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger)
-  if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 3) {   // diagnostic builds (timing only)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps)
+  if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 4 && !a.ev_general) {   // diagnostic builds (1-3: timing only)
 #define RDC_EVA(X)                                                                                                    \
   hipLaunchKernelGGL((k_tet4_ev<3, 3, X>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger)
-    if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else RDC_EVA(3);
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps)
+    if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else if (a.opt_ablate == 3) RDC_EVA(3); else RDC_EVA(4);
 #undef RDC_EVA
+    return hipGetLastError();
+  }
+  if (a.ev_general) {
+    // every term on: 22 moments, 54 KB of LDS.  Register budget of TWO workgroups per CU (244 registers, no scratch): at three the visit
+    // spills 79 registers (304 B of scratch per lane) and runs 8.8 instead of 3.0 ms on K(119) (profiles/r03_ev_ab_log.md, r03q)
+#define RDC_EVG(MODE)                                                                                                       \
+  hipLaunchKernelGGL((k_tet4_ev<MODE, 2, 0, true>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps)
+    if (a.exp_mode == 3) RDC_EVG(3); else RDC_EVG(0);
+#undef RDC_EVG
     return hipGetLastError();
   }
   if (a.exp_mode == 3) { if (a.opt_ev_occ == 2) RDC_EV(3, 2); else RDC_EV(3, 3); }

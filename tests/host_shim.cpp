@@ -427,13 +427,15 @@ int shim_evc_assemble(int model, const void* params, const double* xyz, const do
 // SAME device functions (pihna_visit, pihna_expand): moments accumulated per cluster, expanded per node block into
 // the LDS image of the CSR segments, segments copied out.  val / rhs must be pre-filled by the caller (entries the
 // lists do not cover stay as they are, which the test detects).
-int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double* u, double* val, double* rhs) {
+}  // extern "C"
+template <bool GEN>
+static int ev_assemble_impl(const rdc_pihna_params* p, const double* xyz, const double* u, double* val, double* rhs) {
+  constexpr int NMT = GEN ? ev::NMG : ev::NM;
   if (!g_ev.ok) return 1;
-  if (!PihnaNoCellTransport::applies(*p)) return 3;
   const PihnaK k = Pihna::derive(*p);
   const bool cube = exp_mode_of(k.ek) == 3;
   const HostPrepEv& E = g_ev;
-  std::vector<double> M((size_t)ev::NM * ev::NBP), R(5 * ev::MAXN), img;
+  std::vector<double> M((size_t)NMT * ev::NBP), R(5 * ev::MAXN), img;
   for (size_t w = 0; w < E.desc.size(); w++) {
     const HostPrepEv::Desc& d = E.desc[w];
     const HostPrepEv::Node* nt = &E.ntab[w * HostPrepEv::MAXN];
@@ -462,18 +464,18 @@ int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double*
           if (i < r && slot >= (int)nt[li[i]].len) return 5;
         }
       }
-      if (cube) ev::pihna_visit<3>(k, X, U, r, sink); else ev::pihna_visit<0>(k, X, U, r, sink);
+      if (cube) ev::pihna_visit<3, EvHostSink, true, GEN>(k, X, U, r, sink); else ev::pihna_visit<0, EvHostSink, true, GEN>(k, X, U, r, sink);
     }
     img.assign(d.out_doubles, 0.0);
     for (uint32_t t = 0; t < (uint32_t)ev::NBP; t++) {
       const uint32_t bn = t & (ev::MAXN - 1), s2 = t >> 4;
       if (bn >= d.nown || s2 >= nt[bn].len) continue;
-      double e[ev::NM], o[25];
-      for (int m = 0; m < ev::NM; m++) e[m] = M[(size_t)m * ev::NBP + t];
+      double e[NMT], o[25];
+      for (int m = 0; m < NMT; m++) e[m] = M[(size_t)m * ev::NBP + t];
       const uint32_t mir = E.bpart[w * ev::NBP + t];
       if (mir != t)
-        for (int m = 0; m < ev::NM; m++)
-          if (ev::symmetric_moment(m)) e[m] += M[(size_t)m * ev::NBP + mir];
+        for (int m = 0; m < NMT; m++)
+          if (GEN ? ev::symmetric_moment_gen(m) : ev::symmetric_moment(m)) e[m] += M[(size_t)m * ev::NBP + mir];
       ev::pihna_expand(k, e, o);
       const HostPrepEv::Node& nd = nt[bn];
       for (int a = 0; a < 5; a++)
@@ -491,6 +493,15 @@ int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double*
     }
   }
   return 0;
+}
+extern "C" {
+// shipped parameter pattern: the 16-moment kernel; anything else: all 22 moments (rdc_tet4_ev.h, GEN); gen = 1 forces the latter
+int shim_ev_assemble_gen(const rdc_pihna_params* p, const double* xyz, const double* u, double* val, double* rhs, int gen) {
+  if (gen || !PihnaNoCellTransport::applies(*p)) return ev_assemble_impl<true>(p, xyz, u, val, rhs);
+  return ev_assemble_impl<false>(p, xyz, u, val, rhs);
+}
+int shim_ev_assemble(const rdc_pihna_params* p, const double* xyz, const double* u, double* val, double* rhs) {
+  return shim_ev_assemble_gen(p, xyz, u, val, rhs, 0);
 }
 const char* shim_prep_error() { return g_err.c_str(); }
 // gather lists of the two-pass solid assembly, from the last shim_prep_build

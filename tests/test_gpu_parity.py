@@ -398,7 +398,8 @@ def test_two_rank_partitioned_assembly():
                                   {"kernel": 1}, {"occupancy": 1}, {"xcd": 1}, {"prefetch": 16}, {"specialise": 0}, {"moments": 0},
                                   {"stagger": 8}, {"kernel": 6, "grid": 5}, {"kernel": 6, "grid": 5, "moments": 0},
                                   {"ev_persistent": 1}, {"ev_persistent": 1, "grid": 5}, {"ev_persistent": 1, "grid": 1},
-                                  {"ev_resident": 1}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1}])
+                                  {"ev_resident": 1}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1},
+                                  {"ev_resident": 2}, {"ev_resident": 2, "grid": 7}, {"ev_resident": 2, "grid": 1}, {"ev_resident": 2, "grid": 100000}])
 def test_pihna_option_sets(oracle, opts):
     """Every non-default kernel selection (rdc_set_option) of the PIHNA/TET4 path stays on the oracle."""
     conn, xyz = synth.kuhn_tet_mesh(9, order="lex")
@@ -411,6 +412,40 @@ def test_pihna_option_sets(oracle, opts):
         ctx.mesh_upload(4, conn, xyz, 5)
         ctx.field_upload(FIELD_OLD_SOLUTION, u)
         ctx.assemble_pihna(p)
+        val, rhs = ctx.csr_download()
+    assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
+
+
+@pytest.mark.parametrize("pvariant", ["full", "realexp", "taxis_v_only"])
+@pytest.mark.parametrize("opts", [{}, {"ev_occupancy": 2}, {"ev_general": 0}, {"specialise": 0}, {"part": 1}])
+def test_pihna_general_parameter_kernels(oracle, pvariant, opts):
+    """PIHNA / TET4 with any parameter values: the element-visit kernel with all 22 moments (default, at both register budgets),
+    the pair kernel it replaced ("ev_general" = 0), and the general kernel on the shipped values ("specialise" = 0)."""
+    conn, xyz = synth.kuhn_tet_mesh(10, order="random")
+    u = synth.pihna_fields(xyz)
+    if pvariant == "taxis_v_only":
+        d = synth.pihna_param_dict("shipped")
+        d.update({"taxis/v": 0.3, "uptake/a/from/v": 2.0e-5})
+    else:
+        d = synth.pihna_param_dict("shipped" if "specialise" in opts else pvariant)
+    p = pihna_params_from_dict(d)
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    with AssemblyContext(0) as ctx:
+        two_part = opts.get("part", 0)
+        if two_part:
+            ctx.set_option("interior_nodes", int(0.4 * xyz.shape[0]))
+        for k, v in opts.items():
+            if k != "part":
+                ctx.set_option(k, v)
+        ctx.mesh_upload(4, conn, xyz, 5)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        ctx.timing_enable(True)
+        if two_part:
+            ctx.assemble_pihna_part(p, 1)
+            assert ctx.part1_nodes() > 0                     # the element-visit lists serve the two parts of the general kernel too
+            ctx.assemble_pihna_part(p, 2)
+        else:
+            ctx.assemble_pihna(p)
         val, rhs = ctx.csr_download()
     assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
 

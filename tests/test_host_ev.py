@@ -13,7 +13,7 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _ev(shim, conn, xyz, u, p, n_owned, budget=54000):
+def _ev(shim, conn, xyz, u, p, n_owned, budget=54000, gen=0):
     conn = np.ascontiguousarray(conn, dtype=np.uint32)
     rc = shim.shim_prep_build(4, C.c_int64(conn.shape[0]), C.c_int64(xyz.shape[0]), C.c_int64(n_owned),
                               conn.ctypes.data_as(C.POINTER(C.c_uint32)), 5, C.c_int64(60 * 1024), 256)
@@ -30,7 +30,7 @@ def _ev(shim, conn, xyz, u, p, n_owned, budget=54000):
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     xyz = np.ascontiguousarray(xyz, dtype=np.float64)
     u = np.ascontiguousarray(u, dtype=np.float64)
-    rc = shim.shim_ev_assemble(C.byref(p), dp(xyz), dp(u), dp(val), dp(rhs))
+    rc = shim.shim_ev_assemble_gen(C.byref(p), dp(xyz), dp(u), dp(val), dp(rhs), int(gen))
     assert rc == 0, rc
     return val, rhs, dict(n_wg=n_wg, n_vis=n_vis, n_rows=n_rows, nls=nls, max_out=max_out)
 
@@ -53,6 +53,25 @@ def test_ev_replay_matches_oracle(oracle, shim, order, pvariant):
     assert conn.shape[0] <= st["n_vis"] <= st["n_rows"]
     if order == "lex":
         assert st["n_rows"] / st["n_vis"] > 1.5
+
+
+@pytest.mark.parametrize("order", ["lex", "random"])
+@pytest.mark.parametrize("pvariant,gen", [("full", 0), ("realexp", 0), ("shipped", 1), ("taxis_v_only", 0), ("diffuse_c_only", 0), ("taxis_h_only", 0)])
+def test_ev_replay_general_parameters(oracle, shim, order, pvariant, gen):
+    """Every term of the model on (22 moments, rdc_tet4_ev.h GEN), single transport terms, and the general kernel on the shipped values."""
+    conn, xyz = synth.kuhn_tet_mesh(7, order=order)
+    u = synth.pihna_fields(xyz)
+    if pvariant in ("full", "realexp", "shipped"):
+        d = synth.pihna_param_dict(pvariant)
+    else:
+        d = synth.pihna_param_dict("shipped")
+        d.update({"taxis_v_only": {"taxis/v": 0.3, "uptake/a/from/v": 2.0e-5}, "diffuse_c_only": {"diffuse/c": 0.2},
+                  "taxis_h_only": {"taxis/h": 0.15}}[pvariant])
+    p = pihna_params_from_dict(d)
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    val, rhs, st = _ev(shim, conn, xyz, u, p, xyz.shape[0], gen=gen)
+    assert np.isfinite(val).all() and np.isfinite(rhs).all()
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
 
 
 def test_ev_replay_on_a_ghosted_partition(oracle, shim):
