@@ -257,6 +257,41 @@ def handback(ctx, assemble, n_owned, nnz, n_rows, kern_ms, reps=3):
                     "(rdc_csr_values_device_ptr) avoids this copy altogether"}
 
 
+def state_sensitivity(ctx, p, xyz, u_t, b_alg, reps=10):
+    """The element-visit kernel takes a short cut for waves all of whose elements are in the BACKGROUND state of the reference's
+    shipped field file (n = c = h = a = 0, v > 0: the moments that are sums of exact zeros are not evaluated).  The headline state
+    (tumour inside a sphere r = 0.25, background elsewhere) has 93 % such elements -- the shipped file 99.9 % --, so the
+    kernel time depends on the state.  Timed here on the same mesh: (a) the same state with the short cut off, (b) a DENSE state
+    (tumour values at every node: no background element), short cut on and off.  Kernel times by HIP events, as the headline."""
+    import torch
+    from rdcfes_amd import synth
+
+    def run(label):
+        for _ in range(3):
+            ctx.assemble_pihna(p)
+        ctx.synchronize()
+        ctx.timing_enable(True)
+        for _ in range(reps):
+            ctx.assemble_pihna(p)
+        ms, k = ctx.timing_sum_ms()
+        ctx.timing_enable(False)
+        return {"state": label, "kernel_ms": ms / k, "roofline_frac": b_alg / (ms / k * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+    out = []
+    keep = u_t.clone()
+    bg = ((keep[:, [0, 1, 2, 4]] == 0).all(dim=1) & (keep[:, 3] > 0)).double().mean().item()
+    ctx.set_option("ev_background", 0)
+    out.append(run(f"headline state ({bg:.1%} of the nodes in the background state), short cut OFF"))
+    dense = torch.from_numpy(np.ascontiguousarray(synth.pihna_fields(xyz, radius=10.0))).to(u_t.device)
+    u_t.copy_(dense)
+    out.append(run("dense state (tumour values at every node), short cut OFF"))
+    ctx.set_option("ev_background", 1)
+    out.append(run("dense state (tumour values at every node), short cut ON (its test costs time, nothing is skipped)"))
+    u_t.copy_(keep)
+    ctx.synchronize()
+    return out
+
+
 def two_part_host_cost(ctx, p, n_owned, steps=50):
     """What the two-part step of the N > 1 path costs the HOST at N = 1 (no communication): two C-ABI calls per step
     (rdc_assemble_pihna_part on the main and on a side stream, the stream joins in between as in the N > 1 step) against
@@ -463,6 +498,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=60, help="K(m) sample for the 1-core CPU baseline (0 = skip it)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="N = 1: time the oracle on the benchmark mesh with all host cores and "
                     "report the parity residual of the GPU result against it (0 = skip)")
+    ap.add_argument("--state-check", type=int, default=1, help="N = 1: also time the kernel on a dense state and with the background short cut off")
     ap.add_argument("--configs", type=int, default=1, help="N = 1: also time the other BASELINE configurations (0 = skip)")
     ap.add_argument("--configs-only", type=int, default=0, help="1: run ONLY the other BASELINE configurations and print their array (the command "
                     "tools/make_profiles_configs.sh profiles)")
@@ -606,7 +642,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"PIHNA TET4 K({a.n}): {n_elem_global} tets, {n_node_global} nodes, 5 unknowns, "
-                                   f"params run/PIHNA/input.dat ({a.params}), order={a.order}",
+                                   f"params run/PIHNA/input.dat ({a.params}), order={a.order}, state of SURVEY App. C (background "
+                                   f"(0,0,0,7170,0) of the shipped field file, tumour values inside a sphere r = 0.25; see state_sensitivity)",
                        "scatter": ["auto", "coloured", "rowgather"][ctx.get_scatter()], "kernel_variant": a.variant, "options": a.opt,
                        "parallelism": (f"element partition x{world}, 1 ghost layer, halo p2p over " + ("RCCL" if a.backend == "nccl" else "gloo (host-staged rehearsal)") + (", overlapped with interior rows" if overlap else "")) if world > 1 else "single GPU",
                        "rank0_local_elements": int(l_conn.shape[0]), "rank0_nnz": int(nnz)},
@@ -629,6 +666,8 @@ def main():
                 gpu_val, gpu_rhs = ctx.csr_download()     # the result of the last timed step
             if a.two_part:
                 out["two_part_host"] = two_part_host_cost(ctx, p, n_owned)
+            if a.state_check and a.params == "shipped" and not a.opt:
+                out["state_sensitivity"] = state_sensitivity(ctx, p, l_xyz, u_t, b_alg)
             if a.handback:
                 out["handback"] = handback(ctx, lambda: ctx.assemble_pihna(p), n_owned, nnz, n_rows, kern_avg_ms)
                 # end to end when the adapter downloads the CSR every step (never `value`: inputs and outputs of the metric stay in HBM)

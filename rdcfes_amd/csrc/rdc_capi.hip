@@ -66,6 +66,7 @@ struct rdc_ctx {
   hipEvent_t solid_part1_event = nullptr;   // recorded behind part 1 of a two-part solid assembly (the sides of part 2 wait for it)
   bool solid_part1_pending = false;
   int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
+  int opt_ev_bg = 1;               // 1 = the element-visit kernel skips the zero moments of waves in the background state (n = c = h = a = 0), 0 = evaluates everything
   int opt_ev_general = 1;          // 1 = PIHNA / TET4 with any parameter values through the element-visit kernel with 22 moments; 0 = pair kernel (k_tet4_rg5<Pihna>)
   int opt_ev_resident = 0;         // 1 = k_tet4_evl (resident workgroups, next node list prefetched; experimental)
   int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
@@ -474,6 +475,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_evc_occ = c->opt_evc_occ;
   a.opt_ev_persist = c->opt_ev_persist;
   a.opt_ev_resident = c->opt_ev_resident;
+  a.opt_ev_bg = c->opt_ev_bg;
   a.ev_grid = c->opt_grid > 0 ? c->opt_grid : 2 * c->n_cu;
   if (c->opt_kernel == 5 || c->opt_kernel == 7) a.opt_kernel = 0;
   if (a.use_ev) {
@@ -728,6 +730,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     c->opt_solid_cl_waves = value;
   }
   else if (!std::strcmp(key, "ev_persistent")) c->opt_ev_persist = value ? 1 : 0;   // element-visit kernel walking over the clusters (loader wave + compute waves)
+  else if (!std::strcmp(key, "ev_background")) c->opt_ev_bg = value ? 1 : 0;   // element-visit kernel: skip the moments that are sums of zeros in the background state (1, default)
   else if (!std::strcmp(key, "ev_general")) c->opt_ev_general = value ? 1 : 0;   // general-parameter PIHNA / TET4: element-visit kernel with 22 moments (1, default) or the pair kernel (0)
   else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value == 2 ? 2 : (value ? 1 : 0);   // element-visit kernel as three resident workgroups per CU (k_tet4_evl)
   else if (!std::strcmp(key, "evc_occupancy")) c->opt_evc_occ = value == 3 ? 3 : 2;   // k_tet4_evc: waves per SIMD its registers are bounded for

@@ -49,8 +49,15 @@ constexpr bool symmetric_moment_gen(int m) { return m != M_Epv && m != M_Edd && 
 //   Z_c(i,j) = dd_ij sum_q JxW_q T tax_c Tau c                              -> block (c, v)       (D[1][3])
 // (transport coefficients thresholded per point, src/pihna.C:504-509), the same for h, and for taxis/v: B[3][b][3] joins M_Epv,
 // the extra of B[3][3][3] joins M_Edd (both feed block (v, v) only), D[3][4] joins M_Eg4 (block (v, a)).
+//
+// bg ("background"): the caller knows that n = c = h = a = 0 and v > 0 at the four vertices of every visit it passes together (the
+// device: of every active lane of the wave -- a scalar branch).  Then Ve = 1 and 1 - Ve = 0 (src/pihna.C:474-499), and the nine
+// moments E(1-Ve), E(P h), E(Q h), E(n), E(c), E(h), x, y, E(dTau c), the transport moments of the c and h rows and the right-hand
+// sides of the n, c, h, a equations are sums of exact zeros: they are not evaluated and nothing is added for them.  The shipped
+// initial field (run/PIHNA/Brain_Model_Initial_Nodal_Field.dat) is this state at 24,880 of its 24,903 nodes.
+// (a run-time flag: as two instantiations inlined side by side the kernel spills 30 registers instead of 3.)
 template <int EXP_MODE, class Sink, bool MIRROR = true, bool GEN = false>
-RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (&U)[4][5], const int r, Sink& sink) {
+RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (&U)[4][5], const int r, Sink& sink, const bool bg = false) {
   // ---- geometry: unscaled cofactors g_j = det * grad phi_j ------------------------------------------------------
   double e1[3], e2[3], e3[3];
 #pragma unroll
@@ -191,7 +198,7 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
     }
   }
   // ---- cell transport (GEN): rows c (species 1) and h (species 2), gradient fields (own, v) ---------------------------------
-  if (GEN) {
+  if (GEN && !bg) {
 #pragma unroll
     for (int sp = 1; sp <= 2; sp++) {
       const double Tdif = sp == 1 ? k.Tdif_c : k.Tdif_h, Ttax = sp == 1 ? k.Ttax_c : k.Ttax_h;
@@ -241,7 +248,7 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
     }
   }
   // ---- vascular-fraction functions (coef: oneVe, nVe_dc = Ve rV =: P, Ve_dv = oneVe rV =: Q) ----------------------
-  {
+  if (!bg) {
     RDC_EV_PT(oneVe, 1.0 - s[q].Ve)
     RDC_EV_PT(Pq, s[q].Ve * s[q].rV)
     RDC_EV_PT(Qq, oneVe[q] * s[q].rV)
@@ -271,7 +278,7 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
       RDC_EV_RHS(2, G)
     }
   }
-  {
+  if (!bg) {
     RDC_EV_PT(G, s[q].a + k.Tsec_c * s[q].c + k.Tsec_h * s[q].h - k.Tupt * (s[q].v * s[q].a) - k.Tdec * s[q].a)
     RDC_EV_RHS(4, G)
   }
@@ -281,17 +288,27 @@ RDC_HD void pihna_visit(const PihnaK& k, const double (&X)[4][3], const double (
     const double one[5] = {1.0, 1.0, 1.0, 1.0, 1.0};
     RDC_EV_SYM(M_E1, one)
   }
-  { RDC_EV_PT(b, s[q].n) RDC_EV_SYM(M_En, b) }
-  { RDC_EV_PT(b, s[q].c) RDC_EV_SYM(M_Ec, b) }
-  { RDC_EV_PT(b, s[q].h) RDC_EV_SYM(M_Eh, b) }
+  if (!bg) {
+    { RDC_EV_PT(b, s[q].n) RDC_EV_SYM(M_En, b) }
+    { RDC_EV_PT(b, s[q].c) RDC_EV_SYM(M_Ec, b) }
+    { RDC_EV_PT(b, s[q].h) RDC_EV_SYM(M_Eh, b) }
+    { RDC_EV_PT(b, s[q].dT * s[q].c) RDC_EV_SYM(M_EdTc, b) }
+  }
   { RDC_EV_PT(b, s[q].v) RDC_EV_SYM(M_Ev, b) }
   // E(a) only enters through the uptake rate (pihna_expand: o[23] = Tupt E(a)): with uptake/a/from/v = 0, the shipped value, its ten
   // atomics per visit are not issued (k is uniform: a scalar branch); the slice keeps its zeros and o[23] = 0 * 0
   if (k.Tupt != 0.0) { RDC_EV_PT(b, s[q].a) RDC_EV_SYM(M_Ea, b) }
   { RDC_EV_PT(b, s[q].Tau) RDC_EV_SYM(M_ETau, b) }
-  { RDC_EV_PT(b, s[q].dT * s[q].c) RDC_EV_SYM(M_EdTc, b) }
 #undef RDC_EV_SYM
 #undef RDC_EV_PT
+}
+
+// a visit in the background state (pihna_visit, bg)
+RDC_HD bool pihna_background(const double (&U)[4][5]) {
+  bool b = true;
+#pragma unroll
+  for (int j = 0; j < 4; j++) b = b && U[j][0] == 0.0 && U[j][1] == 0.0 && U[j][2] == 0.0 && U[j][4] == 0.0 && U[j][3] > 0.0;
+  return b;
 }
 
 // The 25 entries of a node block from its 16 moments (e[m]); o[a * 5 + b].  Same formulas as the rows of

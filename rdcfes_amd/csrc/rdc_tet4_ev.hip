@@ -47,7 +47,7 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
           double* __restrict__ rhs, const int nls, const int wg_begin, const int xcd_n, const int stagger,
-          long long* __restrict__ stamps) {
+          long long* __restrict__ stamps, const int bg_skip) {
   constexpr int BLOCK = 256, NP = 4;   // PIHNA node record: 8 doubles = 4 pieces of 16 bytes
   constexpr bool TL = ABL == 4;
   long long ts[11];
@@ -146,7 +146,9 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);   // block (a, slot): slot * 16 + a
     }
-    if (ABL != 3) ev::pihna_visit<EXP_MODE, EvSink<ABL>, true, GEN>(k, X, U, r, sink);   // ABL 3: no compute phase at all (data movement only)
+    // background state (n = c = h = a = 0, v > 0) at every vertex of every visit of this wave: a scalar flag (rdc_tet4_ev.h, bg)
+    const bool bg = bg_skip && __builtin_amdgcn_ballot_w64(!ev::pihna_background(U)) == 0;
+    if (ABL != 3) ev::pihna_visit<EXP_MODE, EvSink<ABL>, true, GEN>(k, X, U, r, sink, bg);   // ABL 3: no compute phase at all (data movement only)
     if (ABL == 2 && sink.sum == 1.2345e300) rhs[0] = sink.sum;  // keeps the arithmetic alive
   }
   if (TL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS atomics have been executed
@@ -836,11 +838,11 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   }
 #define RDC_EV(MODE, MINW)                                                                                          \
   hipLaunchKernelGGL((k_tet4_ev<MODE, MINW>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps, a.opt_ev_bg)
   if (a.exp_mode == 3 && a.opt_ablate >= 1 && a.opt_ablate <= 4 && !a.ev_general) {   // diagnostic builds (1-3: timing only)
 #define RDC_EVA(X)                                                                                                    \
   hipLaunchKernelGGL((k_tet4_ev<3, 3, X>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps, a.opt_ev_bg)
     if (a.opt_ablate == 1) RDC_EVA(1); else if (a.opt_ablate == 2) RDC_EVA(2); else if (a.opt_ablate == 3) RDC_EVA(3); else RDC_EVA(4);
 #undef RDC_EVA
     return hipGetLastError();
@@ -850,7 +852,7 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
     // spills 79 registers (304 B of scratch per lane) and runs 8.8 instead of 3.0 ms on K(119) (profiles/r03_ev_ab_log.md, r03q)
 #define RDC_EVG(MODE)                                                                                                       \
   hipLaunchKernelGGL((k_tet4_ev<MODE, 2, 0, true>), dim3(wg_count), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, \
-                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps)
+                     E.vslot, E.ntab, E.bpart, E.wg_perm, k, a.packed, a.val, a.rhs, E.nls, E.wg_begin, a.opt_xcd ? wg_count : 0, a.opt_stagger, a.stamps, a.opt_ev_bg)
     if (a.exp_mode == 3) RDC_EVG(3); else RDC_EVG(0);
 #undef RDC_EVG
     return hipGetLastError();

@@ -220,16 +220,17 @@ def adpm_fields(xyz, n_elem, seed=SEED):
 
 
 
-def pihna_fields(xyz, seed=SEED):
+def pihna_fields(xyz, seed=SEED, radius=0.25):
     """[n_node][5] (n,c,h,v,a): background (0,0,0,7170,0) as run/PIHNA/Brain_Model_Initial_Nodal_Field.dat,
     a non-degenerate tumour state inside a sphere r=0.25 (v > 0 everywhere: the 0/0 path of
-    src/pihna.C:477 is exercised separately)."""
+    src/pihna.C:477 is exercised separately).  radius > 0.9: the tumour state at every node ("dense" state:
+    no element is in the background state the element-visit kernel takes its short cut for)."""
     rng = np.random.default_rng(seed + 1)
     n = xyz.shape[0]
     u = np.zeros((n, 5))
     u[:, 3] = 7170.0
     r = np.linalg.norm(xyz - 0.5, axis=1)
-    s = r < 0.25
+    s = r < radius
     k = int(s.sum())
     u[s, 0] = rng.uniform(0, 5e2, k)
     u[s, 1] = rng.uniform(0, 2e3, k)

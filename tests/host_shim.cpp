@@ -109,6 +109,7 @@ int masks(const P* p, const double* u, const double* aux, double* worst) {
 
 HostPrep g_prep;
 HostPrepEv g_ev;
+int g_ev_bg = 1;   // shim_ev_assemble: background visits skip their zero moments (rdc_tet4_ev.h, bg), as the device does per wave
 HostPrepCl g_cl;
 std::vector<uint32_t> g_conn;
 SolidGather g_gather;
@@ -427,6 +428,7 @@ int shim_evc_assemble(int model, const void* params, const double* xyz, const do
 // SAME device functions (pihna_visit, pihna_expand): moments accumulated per cluster, expanded per node block into
 // the LDS image of the CSR segments, segments copied out.  val / rhs must be pre-filled by the caller (entries the
 // lists do not cover stay as they are, which the test detects).
+void shim_ev_set_background(int on) { g_ev_bg = on; }
 }  // extern "C"
 template <bool GEN>
 static int ev_assemble_impl(const rdc_pihna_params* p, const double* xyz, const double* u, double* val, double* rhs) {
@@ -464,7 +466,8 @@ static int ev_assemble_impl(const rdc_pihna_params* p, const double* xyz, const 
           if (i < r && slot >= (int)nt[li[i]].len) return 5;
         }
       }
-      if (cube) ev::pihna_visit<3, EvHostSink, true, GEN>(k, X, U, r, sink); else ev::pihna_visit<0, EvHostSink, true, GEN>(k, X, U, r, sink);
+      const bool bg = g_ev_bg && ev::pihna_background(U);   // per visit here, per wave on the device
+      if (cube) ev::pihna_visit<3, EvHostSink, true, GEN>(k, X, U, r, sink, bg); else ev::pihna_visit<0, EvHostSink, true, GEN>(k, X, U, r, sink, bg);
     }
     img.assign(d.out_doubles, 0.0);
     for (uint32_t t = 0; t < (uint32_t)ev::NBP; t++) {

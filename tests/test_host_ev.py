@@ -74,6 +74,31 @@ def test_ev_replay_general_parameters(oracle, shim, order, pvariant, gen):
     assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
 
 
+@pytest.mark.parametrize("pvariant", ["shipped", "full"])
+def test_ev_replay_background_skip(oracle, shim, pvariant):
+    """Visits in the background state (n = c = h = a = 0, v > 0 at their four vertices) skip the moments that are sums of exact
+    zeros: same matrix as with everything evaluated (and as the oracle), with most visits of the synthetic state skipping."""
+    conn, xyz = synth.kuhn_tet_mesh(8, order="random")
+    u = synth.pihna_fields(xyz)
+    bgn = (u[:, [0, 1, 2, 4]] == 0).all(1) & (u[:, 3] > 0)
+    assert 0.5 < bgn[conn].all(1).mean() < 1.0                 # most elements are background, some are not
+    p = pihna_params_from_dict(synth.pihna_param_dict(pvariant))
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u)
+    shim.shim_ev_set_background(0)
+    try:
+        val_all, rhs_all, _ = _ev(shim, conn, xyz, u, p, xyz.shape[0])
+    finally:
+        shim.shim_ev_set_background(1)
+    val, rhs, _ = _ev(shim, conn, xyz, u, p, xyz.shape[0])
+    assert rel(val, val0) < 1e-10 and rel(rhs, rhs0) < 1e-10
+    assert rel(val, val_all) < 1e-14 and rel(rhs, rhs_all) < 1e-14
+    # rows of nodes all of whose elements are background: the n, c, h, a right-hand sides are exactly 0, as upstream
+    quiet = np.ones(xyz.shape[0], bool)
+    quiet[np.unique(conn[~bgn[conn].all(1)])] = False
+    assert quiet.sum() > 100 and np.all(rhs.reshape(-1, 5)[quiet][:, [0, 1, 2, 4]] == 0.0)
+    assert np.all(rhs0.reshape(-1, 5)[quiet][:, [0, 1, 2, 4]] == 0.0)
+
+
 def test_ev_replay_on_a_ghosted_partition(oracle, shim):
     conn, xyz = synth.kuhn_tet_mesh(6, order="random")
     u = synth.pihna_fields(xyz)

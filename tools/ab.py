@@ -17,12 +17,13 @@ ap.add_argument("--params", default="shipped")
 ap.add_argument("--model", default="pihna")
 ap.add_argument("--order", default="lex")
 ap.add_argument("--scatter", type=int, default=2)
+ap.add_argument("--dense", type=int, default=0, help="PIHNA: tumour state at every node (no background elements)")
 ap.add_argument("sets", nargs="+")
 a = ap.parse_args()
 conn, xyz = synth.kuhn_tet_mesh(a.n, order=a.order)
 ctx = AssemblyContext(0)
 if a.model == "pihna":
-    p, u, aux, nv = pihna_params_from_dict(synth.pihna_param_dict(a.params)), synth.pihna_fields(xyz), None, 5
+    p, u, aux, nv = pihna_params_from_dict(synth.pihna_param_dict(a.params)), synth.pihna_fields(xyz, radius=10.0 if a.dense else 0.25), None, 5
     run = ctx.assemble_pihna
 elif a.model == "ripf":
     p, nv = ripf_params_from_dict(synth.ripf_param_dict(a.params)), 3
@@ -54,7 +55,7 @@ res = {s: [] for s in a.sets}
 cur_block = 2561
 for r in range(a.rounds):
     for s in a.sets:
-        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0); ctx.set_option("specialise", 1); ctx.set_option("slim", 0); ctx.set_option("moments", 1); ctx.set_option("prefetch", 0); ctx.set_option("stagger", 0); ctx.set_option("lds_pad", 0); ctx.set_option("grid", 0); ctx.set_option("ev_occupancy", 3); ctx.set_option("ev_persistent", 0); ctx.set_option("evc_occupancy", 2); ctx.set_option("ev_resident", 0); ctx.set_option("xcd", 0); ctx.set_option("ev_general", 1)
+        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0); ctx.set_option("specialise", 1); ctx.set_option("slim", 0); ctx.set_option("moments", 1); ctx.set_option("prefetch", 0); ctx.set_option("stagger", 0); ctx.set_option("lds_pad", 0); ctx.set_option("grid", 0); ctx.set_option("ev_occupancy", 3); ctx.set_option("ev_persistent", 0); ctx.set_option("evc_occupancy", 2); ctx.set_option("ev_resident", 0); ctx.set_option("xcd", 0); ctx.set_option("ev_general", 1); ctx.set_option("ev_background", 1)
         opts = dict(kv.split("=") for kv in s.split(",") if "=" in kv)
         blk = int(opts.pop("block", 256)) * 10 + int(opts.pop("schedule", 1))
         if blk != cur_block:  # work lists depend on the workgroup size / schedule: rebuild
