@@ -6,7 +6,7 @@ tag=${1:-r01}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="bench.py --steps 10 --warmup 3 --cpu-baseline 0 --configs 0 --handback 0 --two-part 0"
+ARGS="bench.py --steps 10 --warmup 3 --cpu-baseline 0 --configs 0 --handback 0 --two-part 0 --state-check 0"
 # 1. kernel trace + stats of the bench command itself (no counters in this run)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $ARGS > $out/bench_under_rocprof.json 2> $out/stats.err
 # 2. counters, each set in its own run (no trace domains besides kernel-trace)
