@@ -82,6 +82,9 @@ RDC_HD void tet4_visit(const typename M::K& k, const double (&X)[4][3], const do
       M::template point<EXP_MODE>(k, uq, aq, pt[q]);
     }
   }
+  // weights folded with the rule's constants once per visit (phi_j(c) = 1/4, phi_j(h_k) = 1/6 + delta_jk/3); the hot-point parts of
+  // S and FS are half the sums of t and f (Wh/36 = (Wh/18)/2, Wh/6 = (Wh/3)/2): one multiplication per point and coefficient
+  const double Wc16 = Wc * (1.0 / 16.0), Wh18 = Wh * (1.0 / 18.0), Wc4 = Wc * 0.25, Wh3 = Wh * (1.0 / 3.0);
   const double W[5] = {Wc, Wh, Wh, Wh, Wh};
   // ---- one equation row at a time: point coefficients -> (S, t), (FS, f), Ds per block -> entries of every owned row -----------
 #pragma unroll
@@ -107,21 +110,35 @@ RDC_HD void tet4_visit(const typename M::K& k, const double (&X)[4][3], const do
 #pragma unroll
       for (int b = 0; b < NV; b++) {
         if (M::hasA(a, b)) {
-          const double wa = W[q] * c.A[a][b];
-          if (q == 0) Sb[b] += wa * (1.0 / 16.0);
-          else { Sb[b] += wa * (1.0 / 36.0); tb[b][q == 0 ? 0 : q - 1] = wa * (1.0 / 18.0); }
+          if (q == 0) Sb[b] = Wc16 * c.A[a][b];
+          else tb[b][q == 0 ? 0 : q - 1] = Wh18 * c.A[a][b];
         }
 #pragma unroll
         for (int g = 0; g < NG; g++)
           if (M::hasB(a, b, g)) {
-            const double wb = W[q] * c.B[a][b][g];
-            if (q == 0) FS[b][g] += wb * 0.25;
-            else { FS[b][g] += wb * (1.0 / 6.0); fb[b][g][q == 0 ? 0 : q - 1] = wb * (1.0 / 3.0); }
+            if (q == 0) FS[b][g] = Wc4 * c.B[a][b][g];
+            else fb[b][g][q == 0 ? 0 : q - 1] = Wh3 * c.B[a][b][g];
           }
         if (M::hasD(a, b)) Ds[b] += W[q] * c.D[a][b];
       }
     }
+#pragma unroll
+    for (int b = 0; b < NV; b++) {
+      if (M::hasA(a, b)) Sb[b] += 0.5 * ((tb[b][0] + tb[b][1]) + (tb[b][2] + tb[b][3]));
+#pragma unroll
+      for (int g = 0; g < NG; g++)
+        if (M::hasB(a, b, g)) FS[b][g] += 0.5 * ((fb[b][g][0] + fb[b][g][1]) + (fb[b][g][2] + fb[b][g][3]));
+    }
     const double Rs = Rc * 0.25 + ((Rh[0] + Rh[1]) + (Rh[2] + Rh[3])) * (1.0 / 6.0);
+    // F_j = FS + f_j is the same for every row of the visit: formed once, in place
+#pragma unroll
+    for (int b = 0; b < NV; b++)
+#pragma unroll
+      for (int g = 0; g < NG; g++)
+        if (M::hasB(a, b, g)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) fb[b][g][j] += FS[b][g];
+        }
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (i < r) {
@@ -147,7 +164,7 @@ RDC_HD void tet4_visit(const typename M::K& k, const double (&X)[4][3], const do
             if (M::hasA(a, b)) v = (j == i) ? Sb[b] + 4.0 * tb[b][i] : Sb[b] + tb[b][i] + tb[b][j];
 #pragma unroll
             for (int g = 0; g < NG; g++)
-              if (M::hasB(a, b, g)) v += gk[g] * (FS[b][g] + fb[b][g][j]);
+              if (M::hasB(a, b, g)) v += gk[g] * fb[b][g][j];
             if (M::hasD(a, b)) v += dd[j] * Ds[b];
             sink.ke(a, b, i, j, v);
           }
