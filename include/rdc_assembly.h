@@ -195,8 +195,8 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * transport off), 0 in coefficient form -- same sums, other association; "specialise": 0 disables that parameter-
  * pattern variant altogether; "kernel", "staged", "slim", "stagger", "prefetch", "xcd", "schedule", "block", "grid",
  * "ev_occupancy", "ev_lds", "evc_occupancy", "ev_persistent" (1 = the element-visit kernel as two resident workgroups per CU with a
- * loader wave), "ev_resident" (1 = as three resident workgroups per CU that load the next cluster's node list one cluster
- * ahead, 2 = that fetch the whole next cluster by LDS-DMA while the current one is expanded and copied out) -- experimental and
+ * loader wave), "ev_resident" (1 = as three resident workgroups per CU that fetch the whole next cluster by LDS-DMA while the
+ * current one is expanded and copied out) -- experimental and
  * slower than the default -- select alternative / diagnostic kernels.  PIHNA / TET4, element-visit kernel:
  * "ev_general" 1 (default) = any parameter values through the kernel with all 22 moments, 0 = through the (node, element) pair
  * kernel as before round 3; "ev_background" 1 (default) = waves all of whose elements are in the background state of the shipped
@@ -389,7 +389,7 @@ int rdc_timing_samples_ms(rdc_ctx* ctx, float* ms, int capacity, int* n_calls);
  * runs a separately compiled kernel that records s_memtime stamps per workgroup phase; *n_written = number
  * of values), call again with a buffer to fetch them: [workgroup][wave][6] shader-clock stamps.
  * With "kernel" = 7 and "ablate" = 4 set before arming, the stamped build is the element-visit kernel itself (results
- * unchanged): [cluster][wave][12] = 11 stamps + hardware id (tools/ev_timeline.py; "ev_resident" = 2: 6 stamps per cluster). */
+ * unchanged): [cluster][wave][12] = 11 stamps + hardware id (tools/ev_timeline.py; "ev_resident" = 1: 6 stamps per cluster). */
 int rdc_debug_stamps(rdc_ctx* ctx, long long* host_out, int64_t capacity, int64_t* n_written);
 
 #ifdef __cplusplus

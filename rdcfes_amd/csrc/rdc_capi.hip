@@ -68,7 +68,7 @@ struct rdc_ctx {
   int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
   int opt_ev_bg = 1;               // 1 = the element-visit kernel skips the zero moments of waves in the background state (n = c = h = a = 0), 0 = evaluates everything
   int opt_ev_general = 1;          // 1 = PIHNA / TET4 with any parameter values through the element-visit kernel with 22 moments; 0 = pair kernel (k_tet4_rg5<Pihna>)
-  int opt_ev_resident = 0;         // 1 = k_tet4_evl (resident workgroups, next node list prefetched; experimental)
+  int opt_ev_resident = 0;         // 1 = k_tet4_evq (resident workgroups that fetch the next cluster while this one is expanded; experimental)
   int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
   int opt_evc_occ = 2;             // ... of the coefficient-form element-visit kernel (k_tet4_evc): 2 (default) or 3 (spills: measured 2.24 vs 1.42 ms)
@@ -732,7 +732,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "ev_persistent")) c->opt_ev_persist = value ? 1 : 0;   // element-visit kernel walking over the clusters (loader wave + compute waves)
   else if (!std::strcmp(key, "ev_background")) c->opt_ev_bg = value ? 1 : 0;   // element-visit kernel: skip the moments that are sums of zeros in the background state (1, default)
   else if (!std::strcmp(key, "ev_general")) c->opt_ev_general = value ? 1 : 0;   // general-parameter PIHNA / TET4: element-visit kernel with 22 moments (1, default) or the pair kernel (0)
-  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value == 2 ? 2 : (value ? 1 : 0);   // element-visit kernel as three resident workgroups per CU (k_tet4_evl)
+  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value ? 1 : 0;   // element-visit kernel as three resident, pipelined workgroups per CU (k_tet4_evq)
   else if (!std::strcmp(key, "evc_occupancy")) c->opt_evc_occ = value == 3 ? 3 : 2;   // k_tet4_evc: waves per SIMD its registers are bounded for
   else if (!std::strcmp(key, "ev_occupancy")) c->opt_ev_occ = value;   // element-visit kernel: 3 (default, 168 registers) or 2
   else if (!std::strcmp(key, "ev_lds")) c->opt_ev_lds = value;   // LDS bytes per workgroup the element-visit clusters are sized for (next rdc_mesh_upload)

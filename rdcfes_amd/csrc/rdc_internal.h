@@ -100,7 +100,7 @@ struct LaunchArgs {
   int opt_ev_persist = 0, ev_grid = 0;   // persistent form of the element-visit kernel (k_tet4_evp) and its grid (workgroups resident at once)
   int opt_ev_bg = 1;         // k_tet4_ev: waves all of whose visits are in the background state skip the moments that are sums of zeros (rdc_tet4_ev.h, bg)
   bool ev_general = false;   // k_tet4_ev with every PIHNA term on (22 moments) instead of the shipped parameter pattern (16)
-  int opt_ev_resident = 0;   // k_tet4_evl: three resident workgroups per CU walking over the clusters (experimental)
+  int opt_ev_resident = 0;   // k_tet4_evq: three resident workgroups per CU walking over the clusters, next cluster fetched ahead (experimental)
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;
   double* rhs;

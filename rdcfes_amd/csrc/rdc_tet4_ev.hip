@@ -219,166 +219,11 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
 }
 
 
-// ---- resident form ("ev_resident" = 1, experimental) ----------------------------------------------------------------------------
-// k_tet4_ev pays, per cluster, for a workgroup launch, TWO dependent round trips at its start (node list -> record DMA) and the
-// drain of its stores at its end (s_endpgm waits for them) -- about 5 of the ~14 us a workgroup lives with three on a CU.  Here
-// three workgroups per CU stay resident and walk over the clusters blockIdx + i * gridDim with NO extra LDS and two more
-// registers: the node list of cluster i + 1 is loaded while cluster i is processed, so at the top of a cluster the list loads
-// and the record DMA are issued together (ONE round trip), right behind the copy-out stores of the previous cluster, which
-// drain meanwhile (the one s_waitcnt vmcnt(0) of a cluster covers both).  Unlike k_tet4_evp (below) there is no loader wave
-// and no second LDS buffer: the records / lists of the next cluster are fetched only once the image of this one has been read.
-// Barriers order LDS only (no wave waits for its stores before issuing the next cluster's loads).
-namespace {
-__device__ __forceinline__ void evl_dma16(const void* g, const void* lds_base) {   // LDS-DMA the compiler does not see (see evp_dma16)
-  const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory", "m0");
-}
-}
-template <int EXP_MODE>
-__global__ void __launch_bounds__(256, 3)
-k_tet4_evl(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
-           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
-           const PihnaK k, const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int nls,
-           const int wg_begin, const int wg_count) {
-  constexpr int BLOCK = 256, NP = 4;
-  constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP | R: 5 x MAXN | records: NP x nls x 16 B], later the CSR image
-  __shared__ HostPrepEv::Node snode[MAXN];
-  double* const R = lds + NM * NBP;
-  double* const recs = R + 5 * MAXN;
-  const int rounds = nls >> 6;
-  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  const int n_it = (wg_count - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid is <= wg_count
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // a scalar: cheap to keep across the loop
-  uint32_t nid = 0;
-  if (wv < rounds) nid = nlist[(size_t)(wg_begin + (int)blockIdx.x) * nls + threadIdx.x];
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(nid)::"memory");
-#pragma unroll 1
-  for (int it = 0; it < n_it; it++) {
-    // NO scratch in this loop: a scratch reload is a vector-memory operation, and its s_waitcnt vmcnt would also wait for the
-    // stores of the previous cluster and the loads of this one -- the thread index is made opaque per iteration so that what is
-    // derived from it (addresses, block coordinates) is recomputed here instead of being hoisted out of the loop and spilled
-    // (the lane index comes from the hardware lane counter, not from the thread-index register, which would otherwise be the value
-    // that is spilled at entry and reloaded here)
-    int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));   // volatile: recomputed every iteration, never hoisted
-    const int tid = wv * 64 + lane;
-    const int w = wg_begin + (int)blockIdx.x + it * (int)gridDim.x;
-    // ---- everything this cluster needs from memory, in one round trip; the node list of the next cluster rides along
-    uint32_t pl = vloc[(size_t)w * BLOCK + tid];
-    uint2 sl = reinterpret_cast<const uint2*>(vslot)[(size_t)w * BLOCK + tid];
-    HostPrepEv::Desc d = desc[w];
-    int mirror = (int)bpart[(size_t)w * NBP + tid];
-    HostPrepEv::Node mynode = {0, 0, 0, 0, 0};
-    if (tid < MAXN) mynode = ntab[(size_t)w * MAXN + tid];
-    if (wv < rounds) {
-      const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid * (NP * 16);
-#pragma unroll
-      for (int p = 0; p < NP; p++) evl_dma16(src + p * 16, recs + (p * nls + wv * 64) * 2);
-    }
-    uint32_t nid_next = 0;
-    if (it + 1 < n_it && wv < rounds) nid_next = nlist[(size_t)(w + (int)gridDim.x) * nls + wv * 64 + lane];
-    {   // zero [M | R] (ds_write_addtid_b32: k_tet4_ev)
-      const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)wv * 8192u;
-      const uint32_t zero = 0u;
-      uint32_t m0_saved;
-#define RDC_Z4(o) "ds_write_addtid_b32 %1 offset:" #o "\n\tds_write_addtid_b32 %1 offset:" #o "+256\n\tds_write_addtid_b32 %1 offset:" #o "+512\n\tds_write_addtid_b32 %1 offset:" #o "+768\n\t"
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   RDC_Z4(0) RDC_Z4(1024) RDC_Z4(2048) RDC_Z4(3072) RDC_Z4(4096) RDC_Z4(5120) RDC_Z4(6144) RDC_Z4(7168)
-                   "s_mov_b32 m0, %0"
-                   : "=&s"(m0_saved) : "v"(zero), "s"(zbase) : "memory");
-#undef RDC_Z4
-      if (tid < 5 * MAXN) lds[NM * NBP + tid] = 0.0;
-    }
-    // the one wait of the cluster: its lists, its records, the next node list -- and the stores of the previous cluster
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pl), "+v"(sl.x), "+v"(sl.y), "+v"(mirror), "+v"(nid_next), "+v"(mynode.bptr), "+v"(mynode.obase), "+v"(mynode.node)::"memory");
-    if (tid < MAXN) snode[tid] = mynode;
-    lds_barrier();
-    // ---- element visits (phase 1 of k_tet4_ev)
-    if (pl != 0xFFFFFFFFu) {
-      double X[4][3], U[4][5];
-      int li[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        li[j] = (pl >> (8 * j)) & 0xFF;
-        double rr[2 * NP];
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-          const double2 v2 = reinterpret_cast<const double2*>(recs)[p * nls + li[j]];
-          rr[2 * p] = v2.x; rr[2 * p + 1] = v2.y;
-        }
-        X[j][0] = rr[0]; X[j][1] = rr[1]; X[j][2] = rr[2];
-#pragma unroll
-        for (int v = 0; v < 5; v++) U[j][v] = rr[3 + v];
-      }
-      const int nown = (int)d.nown;
-      const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
-      EvSink<0> sink;
-      const uint32_t sw[4] = {sl.x & 0xFFFFu, sl.x >> 16, sl.y & 0xFFFFu, sl.y >> 16};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int a = (i < r) ? li[i] : 0;
-        sink.pr[i] = R + a;
-#pragma unroll
-        for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);
-      }
-      ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
-    }
-    lds_barrier();
-    // ---- node block tid = slot * 16 + node: moments -> entries
-    double e[NM];
-    const int bn = tid & (MAXN - 1), bs = tid >> 4;
-    const bool has = bn < (int)d.nown && bs < (int)snode[bn < (int)d.nown ? bn : 0].len;
-#pragma unroll
-    for (int m = 0; m < NM; m++) e[m] = 0.0;   // defined on every path: otherwise the undefined lanes' values are carried around the loop (and spilled)
-    if (has) {
-#pragma unroll
-      for (int m = 0; m < NM; m++) e[m] = lds[m * NBP + tid];
-      if (mirror != tid) {
-#pragma unroll
-        for (int m = 0; m < NM; m++)
-          if (ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
-      }
-    }
-    if (tid < (int)d.nown * 5) {
-      const int n = tid / 5, a = tid - n * 5;
-      rhs[(size_t)snode[n].node * 5 + a] = R[a * MAXN + n];
-    }
-    lds_barrier();   // every moment has been read: the image may overwrite the slice (and the records)
-    if (has) {
-      double o[25];
-      ev::pihna_expand(k, e, o);
-      const int len5 = 5 * (int)snode[bn].len;
-      double* dst = lds + snode[bn].obase + 5 * bs;
-#pragma unroll
-      for (int a = 0; a < 5; a++)
-#pragma unroll
-        for (int b = 0; b < 5; b++) dst[a * len5 + b] = o[a * 5 + b];
-    }
-    lds_barrier();
-    for (int n = wv; n < (int)d.nown; n += 4) {
-      const HostPrepEv::Node nd = snode[n];
-      const int cnt = 25 * (int)nd.len;
-      double* out = val + (size_t)25 * nd.bptr;
-      const double* img = lds + nd.obase;
-      const int sh = (int)(nd.obase & 1);
-      typedef double v2d_t __attribute__((ext_vector_type(2)));
-      const int npair = (cnt - sh) >> 1;
-      const v2d_t* src = reinterpret_cast<const v2d_t*>(img + sh);
-      v2d_t* dstg = reinterpret_cast<v2d_t*>(out + sh);
-      for (int x = lane; x < npair; x += 64) __builtin_nontemporal_store(src[x], dstg + x);
-      if (sh && lane == 0) __builtin_nontemporal_store(img[0], out);
-      if (((cnt - sh) & 1) && lane == 1) __builtin_nontemporal_store(img[cnt - 1], out + cnt - 1);
-    }
-    lds_barrier();   // the image and the node table have been read (into the stores' registers): the next cluster may land
-    nid = nid_next;
-  }
-}
-
-// ---- pipelined resident form ("ev_resident" = 2, experimental) -------------------------------------------------------------------
+// ---- pipelined resident form ("ev_resident" = 1, experimental) -------------------------------------------------------------------
 // The stamped build of k_tet4_ev (tools/ev_timeline.py, K(119)) puts 23 % of a workgroup's life into phase 0 -- list loads, the
 // dependent record DMA, the barrier behind the slowest wave's loads -- during which its LDS and registers do nothing; the
-// stores are not what it waits for at its end (1 %).  Here three workgroups per CU stay resident (as k_tet4_evl) and fetch
+// stores are not what it waits for at its end (1 %).  Here three workgroups per CU stay resident (walking over the clusters
+// blockIdx + i * gridDim; a first form that only loaded the next node list ahead, k_tet4_evl, measured 2.18 vs 2.04 ms and was removed) and fetch
 // cluster i + 1 WHILE cluster i is expanded and copied out: behind the barrier that ends the visits of cluster i every wave
 // issues the LDS-DMA of the records and lists of cluster i + 1 (node ids DMA'd one cluster earlier) and of the node ids of
 // cluster i + 2.  They land during the moment reads, the expansion and the copy-out; the one s_waitcnt vmcnt(0) at the top of a
@@ -387,6 +232,12 @@ k_tet4_evl(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
 // touch scratch (a scratch reload waits for every earlier vector-memory operation of its wave).
 // LDS: the record and list landing areas may not be covered by the CSR image, so the image is built and sent in two halves
 // (nodes 0-7 by waves 0-1, nodes 8-15 by waves 2-3: at most 8 x 16 x 25 doubles, inside the 32 KB moment slice); 46 KB per workgroup.
+namespace {
+__device__ __forceinline__ void evl_dma16(const void* g, const void* lds_base) {   // LDS-DMA the compiler does not see (see evp_dma16)
+  const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory", "m0");
+}
+}
 namespace {
 struct EvqLists {   // landing area of a cluster's lists (bytes): visit positions, column slots, then mirror blocks | node table | descriptor; node ids x 2
   static constexpr int PL = 0, SL = 1024, MISC = SL + 2048, MIRROR = MISC, SNODE = MISC + 256, DESC = MISC + 512, NL = MISC + 544;
@@ -443,7 +294,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
 #pragma unroll 1
   for (int it = 0; it < n_it; it++) {
     int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));   // recomputed every iteration (k_tet4_evl)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));   // recomputed every iteration: never hoisted out of the loop and spilled
     const int w = wg_begin + (int)blockIdx.x + it * (int)gridDim.x;
     RDC_TS(0);
     {   // zero [M | R] (ds_write_addtid_b32: k_tet4_ev); the image of the previous cluster has been read (barrier at its end)
@@ -813,7 +664,7 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t acc = (size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
   const size_t lds_doubles = acc > E.max_out_doubles ? acc : E.max_out_doubles;
   const size_t lds_bytes = lds_doubles * sizeof(double);
-  if (a.opt_ev_resident == 2 && !E.wg_perm && (!a.opt_ablate || a.opt_ablate == 4) && !a.ev_general) {   // pipelined resident workgroups (whole-mesh launches only)
+  if (a.opt_ev_resident && !E.wg_perm && (!a.opt_ablate || a.opt_ablate == 4) && !a.ev_general) {   // pipelined resident workgroups (whole-mesh launches only)
     int grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? a.ev_grid / 2 * 3 : 768);   // three per CU
     if (grid > wg_count) grid = wg_count;
     const size_t bytes = ((size_t)ev::NM * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2) * sizeof(double) + EvqLists::bytes(E.nls);
@@ -823,17 +674,6 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
     if (a.opt_ablate == 4) { if (a.exp_mode == 3) RDC_EVQ(3, true); else RDC_EVQ(0, true); }
     else { if (a.exp_mode == 3) RDC_EVQ(3, false); else RDC_EVQ(0, false); }
 #undef RDC_EVQ
-    return hipGetLastError();
-  }
-  if (a.opt_ev_resident && !E.wg_perm && !a.opt_ablate && !a.ev_general) {   // resident workgroups walking over the clusters (whole-mesh launches only)
-    int grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? a.ev_grid / 2 * 3 : 768);   // three per CU
-    if (grid > wg_count) grid = wg_count;
-    if (a.exp_mode == 3)
-      hipLaunchKernelGGL((k_tet4_evl<3>), dim3(grid), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, a.packed,
-                         a.val, a.rhs, E.nls, E.wg_begin, wg_count);
-    else
-      hipLaunchKernelGGL((k_tet4_evl<0>), dim3(grid), dim3(256), lds_bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, a.packed,
-                         a.val, a.rhs, E.nls, E.wg_begin, wg_count);
     return hipGetLastError();
   }
 #define RDC_EV(MODE, MINW)                                                                                          \

@@ -12,7 +12,7 @@ from rdcfes_amd.context import FIELD_OLD_SOLUTION
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 119
 nodrain = "nodrain" in sys.argv
-evq = "evq" in sys.argv      # the pipelined resident kernel ("ev_resident" = 2): 6 stamps per cluster and wave
+evq = "evq" in sys.argv      # the pipelined resident kernel ("ev_resident" = 1): 6 stamps per cluster and wave
 conn, xyz = synth.kuhn_tet_mesh(n)
 p, u = pihna_params_from_dict(synth.pihna_param_dict("shipped")), synth.pihna_fields(xyz)
 ctx = AssemblyContext(0)
@@ -22,7 +22,7 @@ for _ in range(3): ctx.assemble_pihna(p)
 ctx.synchronize(); ms, k = ctx.timing_sum_ms(); base_ms = ms / k
 val0, rhs0 = ctx.csr_download()
 ctx.set_option("kernel", 7); ctx.set_option("ablate", 4)
-if evq: ctx.set_option("ev_resident", 2)
+if evq: ctx.set_option("ev_resident", 1)
 if nodrain: ctx.set_option("stagger", -1)
 nw = C.c_int64()
 ctx._ck(ctx._lib.rdc_debug_stamps(ctx._h, None, 0, C.byref(nw)))
