@@ -51,7 +51,7 @@ struct rdc_ctx {
   int opt_block = 256;  // workgroup size of the row-gather work lists (takes effect at the next rdc_mesh_upload)
   HostPrep prep;
   HostPrepEv prep_ev;          // element-visit lists (PIHNA TET4, shipped pattern); .ok = available
-  DevBuf ev_desc, ev_nlist, ev_vloc, ev_vslot, ev_ntab, ev_bpart, ev_perm;
+  DevBuf ev_desc, ev_nlist, ev_vloc, ev_vslot, ev_ntab, ev_bpart, ev_perm, ev_ticket;
   bool ev_tried = false;           // the element-visit lists of this mesh have been built (or found impossible)
   int64_t ev_perm_interior = -2;   // "interior_nodes" value the uploaded workgroup order was built for
   int ev_part1_wg = 0;             // leading workgroups of that order whose clusters are interior
@@ -68,7 +68,7 @@ struct rdc_ctx {
   int64_t part1_nodes = -1;        // rows [0, part1_nodes) were complete after the LAST part-1 call (-1: none since the upload)
   int opt_ev_bg = 1;               // 1 = the element-visit kernel skips the zero moments of waves in the background state (n = c = h = a = 0), 0 = evaluates everything
   int opt_ev_general = 1;          // 1 = PIHNA / TET4 with any parameter values through the element-visit kernel with 22 moments; 0 = pair kernel (k_tet4_rg5<Pihna>)
-  int opt_ev_resident = 0;         // 1 = k_tet4_evq (resident workgroups that fetch the next cluster while this one is expanded; experimental)
+  int opt_ev_resident = 1;         // 1 (default) = whole-mesh launches of the shipped-pattern element-visit kernel run as k_tet4_evq (resident workgroups that fetch the next cluster while this one is expanded); 0 = k_tet4_ev
   int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
   int opt_evc_occ = 2;             // ... of the coefficient-form element-visit kernel (k_tet4_evc): 2 (default) or 3 (spills: measured 2.24 vs 1.42 ms)
@@ -476,6 +476,10 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_ev_persist = c->opt_ev_persist;
   a.opt_ev_resident = c->opt_ev_resident;
   a.opt_ev_bg = c->opt_ev_bg;
+  if (c->opt_ev_resident) {   // cluster counter of the resident kernel
+    if ((rc = dev_alloc(c, c->ev_ticket, 64))) return rc;
+    a.ev_ticket = (int*)c->ev_ticket.p;
+  }
   a.ev_grid = c->opt_grid > 0 ? c->opt_grid : 2 * c->n_cu;
   if (c->opt_kernel == 5 || c->opt_kernel == 7) a.opt_kernel = 0;
   if (a.use_ev) {
@@ -649,7 +653,7 @@ int rdc_ctx_destroy(rdc_ctx* c) {
                    &c->rg2_sdesc, &c->rg2_contrib, &c->rg2_aux, &c->rg2_ntab, &c->rg4_nlist, &c->rg4_ploc, &c->rg4_wgntab, &c->rg5_eid, &c->hx_nl_ptr, &c->hx_nlist, &c->hx_ploc,
                    &c->elem_material, &c->materials, &c->side_elem, &c->side_id, &c->side_disp,
                    &c->scl_desc, &c->scl_ntab, &c->scl_eid, &c->scl_pair, &c->scl_pslot, &c->solid_ke, &c->solid_fe, &c->sg_gptr, &c->sg_gsrc, &c->sg_brow, &c->wg_max, &c->solid_post, &c->adpm_slot,
-                   &c->ev_desc, &c->ev_nlist, &c->ev_vloc, &c->ev_vslot, &c->ev_ntab, &c->ev_bpart, &c->ev_perm};
+                   &c->ev_desc, &c->ev_nlist, &c->ev_vloc, &c->ev_vslot, &c->ev_ntab, &c->ev_bpart, &c->ev_perm, &c->ev_ticket};
   for (DevBuf* b : all) dev_free(c, *b);
   for (int f = 0; f < RDC_FIELD_COUNT; f++) dev_free(c, c->field[f]);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -732,7 +736,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "ev_persistent")) c->opt_ev_persist = value ? 1 : 0;   // element-visit kernel walking over the clusters (loader wave + compute waves)
   else if (!std::strcmp(key, "ev_background")) c->opt_ev_bg = value ? 1 : 0;   // element-visit kernel: skip the moments that are sums of zeros in the background state (1, default)
   else if (!std::strcmp(key, "ev_general")) c->opt_ev_general = value ? 1 : 0;   // general-parameter PIHNA / TET4: element-visit kernel with 22 moments (1, default) or the pair kernel (0)
-  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value ? 1 : 0;   // element-visit kernel as three resident, pipelined workgroups per CU (k_tet4_evq)
+  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value ? 1 : 0;   // whole-mesh launches of the element-visit kernel as three resident, pipelined workgroups per CU (k_tet4_evq; default 1)
   else if (!std::strcmp(key, "evc_occupancy")) c->opt_evc_occ = value == 3 ? 3 : 2;   // k_tet4_evc: waves per SIMD its registers are bounded for
   else if (!std::strcmp(key, "ev_occupancy")) c->opt_ev_occ = value;   // element-visit kernel: 3 (default, 168 registers) or 2
   else if (!std::strcmp(key, "ev_lds")) c->opt_ev_lds = value;   // LDS bytes per workgroup the element-visit clusters are sized for (next rdc_mesh_upload)

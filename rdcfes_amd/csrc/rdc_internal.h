@@ -99,8 +99,9 @@ struct LaunchArgs {
   int opt_evc_occ = 2;
   int opt_ev_persist = 0, ev_grid = 0;   // persistent form of the element-visit kernel (k_tet4_evp) and its grid (workgroups resident at once)
   int opt_ev_bg = 1;         // k_tet4_ev: waves all of whose visits are in the background state skip the moments that are sums of zeros (rdc_tet4_ev.h, bg)
+  int* ev_ticket = nullptr;  // k_tet4_evq: cluster counter (one int, zeroed by the launch)
   bool ev_general = false;   // k_tet4_ev with every PIHNA term on (22 moments) instead of the shipped parameter pattern (16)
-  int opt_ev_resident = 0;   // k_tet4_evq: three resident workgroups per CU walking over the clusters, next cluster fetched ahead (experimental)
+  int opt_ev_resident = 1;   // k_tet4_evq: three resident workgroups per CU walking over the clusters, next cluster fetched ahead (whole-mesh launches)
   long long* stamps = nullptr;  // diagnostic phase stamps (rdc_debug_stamps)
   double* val;
   double* rhs;

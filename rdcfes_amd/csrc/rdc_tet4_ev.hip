@@ -249,20 +249,35 @@ __global__ void __launch_bounds__(256, 3)
 k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
            const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
            const PihnaK k, const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int nls,
-           const int wg_begin, const int wg_count, long long* __restrict__ stamps) {
+           const int wg_begin, const int wg_count, long long* __restrict__ stamps, const int bg_skip, int* __restrict__ ticket) {
   constexpr int BLOCK = 256, NP = 4;
   constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP, later the image halves | R: 5 x MAXN | records: NP x nls x 16 B | lists]
   __shared__ HostPrepEv::Node snode[MAXN];
   __shared__ uint8_t smirror[NBP];
   __shared__ int s_nown;
+  __shared__ int s_tk[2];
   double* const R = lds + NM * NBP;
   double* const recs = R + 5 * MAXN;
   char* const lists = reinterpret_cast<char*>(recs + (size_t)NP * nls * 2);
   const int rounds = nls >> 6;
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  const int n_it = (wg_count - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid is <= wg_count
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // Clusters are handed out dynamically: the first one of a workgroup is blockIdx, every later one comes from a global counter
+  // (`ticket`, zero at launch), requested THREE clusters ahead -- the node ids of cluster i + 2 are fetched while cluster i is
+  // expanded -- by lane 0 of wave 0 and passed on through LDS at the barrier at the top of the next cluster.  c0 = this cluster,
+  // c1, c2 = the next two (indices into the launch's range; >= wg_count: none).
+  constexpr int NONE = 0x7fffffff;
+  int c0 = (int)blockIdx.x, c1, c2;
+  {
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(ticket, 2);
+      s_tk[0] = (int)gridDim.x + t; s_tk[1] = (int)gridDim.x + t + 1;
+    }
+    __syncthreads();
+    c1 = __builtin_amdgcn_readfirstlane(s_tk[0]); c2 = __builtin_amdgcn_readfirstlane(s_tk[1]);
+    __syncthreads();
+  }
   long long ts[8];
 #define RDC_TS(x) if (TL) ts[x] = __builtin_amdgcn_s_memtime()
   // everything cluster `w` needs (node ids in `nid`), and the node ids of cluster `w2` into id buffer `nb2`, by LDS-DMA
@@ -285,17 +300,19 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     }
   };
   {
-    const int w0 = wg_begin + (int)blockIdx.x;
+    const int w0 = wg_begin + c0;
     uint32_t nid0 = 0;
     if (wv < rounds) nid0 = nlist[(size_t)w0 * nls + threadIdx.x];
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(nid0)::"memory");
-    fetch(w0, nid0, n_it > 1 ? w0 + (int)gridDim.x : -1, 1, (int)(threadIdx.x & 63));
+    fetch(w0, nid0, c1 < wg_count ? wg_begin + c1 : -1, 1, (int)(threadIdx.x & 63));
   }
+  int tk = NONE;          // lane 0 of wave 0: the ticket requested while the previous cluster was expanded
+  bool pending = false;
 #pragma unroll 1
-  for (int it = 0; it < n_it; it++) {
+  for (int it = 0;; it++) {
     int lane;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));   // recomputed every iteration: never hoisted out of the loop and spilled
-    const int w = wg_begin + (int)blockIdx.x + it * (int)gridDim.x;
+    const int w = wg_begin + c0;
     RDC_TS(0);
     {   // zero [M | R] (ds_write_addtid_b32: k_tet4_ev); the image of the previous cluster has been read (barrier at its end)
       const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)wv * 8192u;
@@ -310,10 +327,13 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
       if (wv * 64 + lane < 5 * MAXN) lds[NM * NBP + wv * 64 + lane] = 0.0;
     }
     // the one wait of the cluster: what was fetched for it while the previous one was expanded -- and that one's stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk)::"memory");
+    if (pending && wv == 0 && lane == 0) s_tk[0] = tk == NONE ? NONE : (int)gridDim.x + tk;
     RDC_TS(1);
     lds_barrier();
     RDC_TS(2);
+    if (pending) c2 = __builtin_amdgcn_readfirstlane(s_tk[0]);
+    if (c0 >= wg_count) break;   // uniform
     {
       const int tid = wv * 64 + lane;
       const uint32_t pl = *reinterpret_cast<const uint32_t*>(lists + EvqLists::PL + tid * 4);
@@ -353,7 +373,8 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
 #pragma unroll
           for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);
         }
-        ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
+        const bool bg = bg_skip && __builtin_amdgcn_ballot_w64(!ev::pihna_background(U)) == 0;   // k_tet4_ev
+        ev::pihna_visit<EXP_MODE, EvSink<0>, true, false>(k, X, U, r, sink, bg);
       }
     }
     RDC_TS(3);
@@ -361,11 +382,20 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     RDC_TS(4);
     // ---- from here to the top of the next cluster: NO scratch (the lane index is taken from the hardware again)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    if (it + 1 < n_it) {
+    if (c1 < wg_count) {
       uint32_t nid = 0;
       if (wv < rounds) nid = *reinterpret_cast<const uint32_t*>(lists + EvqLists::NL + (((it + 1) & 1) * nls + wv * 64 + lane) * 4);
-      fetch(w + (int)gridDim.x, nid, it + 2 < n_it ? w + 2 * (int)gridDim.x : -1, it & 1, lane);
+      fetch(wg_begin + c1, nid, c2 < wg_count ? wg_begin + c2 : -1, it & 1, lane);
     }
+    // the cluster after those two: one ticket per workgroup (nothing left once c2 is past the end: the counter only grows)
+    tk = NONE;
+    if (c2 < wg_count && wv == 0 && lane == 0) {
+      // in asm: the compiler's atomicAdd is a wave-aggregated atomic whose result it broadcasts (and waits for) at once; this one is
+      // waited for by the s_waitcnt vmcnt(0) at the top of the next cluster
+      const int one = 1;
+      asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(tk) : "v"(ticket), "v"(one) : "memory");
+    }
+    pending = true;
     // ---- node block (bn, bs): moments -> entries; waves 0-1 hold the blocks of nodes 0-7, waves 2-3 those of nodes 8-15
     const int nown = s_nown;
     const int bn = ((wv >> 1) << 3) | (lane & 7), bs = ((wv & 1) << 3) | (lane >> 3), blk = bs * MAXN + bn;
@@ -431,6 +461,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
       for (int x = 0; x < 6; x++) op[x] = ts[x];
       op[11] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
+    c0 = c1; c1 = c2;   // c2: from the ticket, behind the barrier at the top
   }
 #undef RDC_TS
 }
@@ -664,13 +695,17 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t acc = (size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
   const size_t lds_doubles = acc > E.max_out_doubles ? acc : E.max_out_doubles;
   const size_t lds_bytes = lds_doubles * sizeof(double);
-  if (a.opt_ev_resident && !E.wg_perm && (!a.opt_ablate || a.opt_ablate == 4) && !a.ev_general) {   // pipelined resident workgroups (whole-mesh launches only)
+  // default for the shipped parameter pattern: pipelined resident workgroups, clusters handed out by a counter.  Not for launches
+  // in a permuted cluster order (two-part assembly: the ticket would need a dependent load), the 22-moment instantiation, or
+  // when a diagnostic knob of k_tet4_ev is set
+  if (a.opt_ev_resident && !E.wg_perm && (!a.opt_ablate || a.opt_ablate == 4) && !a.ev_general && a.opt_ev_occ == 3 && !a.opt_xcd && a.opt_stagger == 0) {
     int grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? a.ev_grid / 2 * 3 : 768);   // three per CU
     if (grid > wg_count) grid = wg_count;
     const size_t bytes = ((size_t)ev::NM * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2) * sizeof(double) + EvqLists::bytes(E.nls);
+    if (!a.ev_ticket) return hipErrorInvalidValue;   // the cluster counter: zeroed by the record pack kernel in front of this launch
 #define RDC_EVQ(MODE, TLV)                                                                                                              \
   hipLaunchKernelGGL((k_tet4_evq<MODE, TLV>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, \
-                     a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, a.stamps)
+                     a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, a.stamps, a.opt_ev_bg, a.ev_ticket)
     if (a.opt_ablate == 4) { if (a.exp_mode == 3) RDC_EVQ(3, true); else RDC_EVQ(0, true); }
     else { if (a.exp_mode == 3) RDC_EVQ(3, false); else RDC_EVQ(0, false); }
 #undef RDC_EVQ

@@ -23,8 +23,9 @@ template <class M> struct Rec {
 // records of nodes [node_begin, node_end)
 template <class M>
 __global__ void k_pack_nodes(int64_t node_begin, int64_t node_end, const double* __restrict__ xyz, const double* __restrict__ u,
-                             const double* __restrict__ aux, double* __restrict__ rec) {
+                             const double* __restrict__ aux, double* __restrict__ rec, int* __restrict__ ticket) {
   constexpr int N = Rec<M>::N, NV = M::NV, NA = M::NAUX;
+  if (ticket && blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;   // cluster counter of the resident element-visit kernel that follows on the stream
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = node_begin * N + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < node_end * N; t += stride) {
     const int64_t n = t / N;
@@ -913,7 +914,7 @@ static hipError_t pack_nodes(const LaunchArgs& a) {
   if (total > 0) {
     int64_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux, a.packed);
+    hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux, a.packed, a.ev_ticket);
   }
   if (a.pack_part == 1 && a.pack_event) (void)hipEventRecord(a.pack_event, a.stream);
   return hipGetLastError();

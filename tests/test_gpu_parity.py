@@ -398,7 +398,7 @@ def test_two_rank_partitioned_assembly():
                                   {"kernel": 1}, {"occupancy": 1}, {"xcd": 1}, {"prefetch": 16}, {"specialise": 0}, {"moments": 0},
                                   {"stagger": 8}, {"kernel": 6, "grid": 5}, {"kernel": 6, "grid": 5, "moments": 0},
                                   {"ev_persistent": 1}, {"ev_persistent": 1, "grid": 5}, {"ev_persistent": 1, "grid": 1},
-                                  {"ev_resident": 1}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1}, {"ev_resident": 1, "grid": 100000}])
+                                  {"ev_resident": 0}, {"ev_resident": 0, "kernel": 7}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1}, {"ev_resident": 1, "grid": 100000}])
 def test_pihna_option_sets(oracle, opts):
     """Every non-default kernel selection (rdc_set_option) of the PIHNA/TET4 path stays on the oracle."""
     conn, xyz = synth.kuhn_tet_mesh(9, order="lex")
