@@ -736,7 +736,7 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
   else if (!std::strcmp(key, "ev_persistent")) c->opt_ev_persist = value ? 1 : 0;   // element-visit kernel walking over the clusters (loader wave + compute waves)
   else if (!std::strcmp(key, "ev_background")) c->opt_ev_bg = value ? 1 : 0;   // element-visit kernel: skip the moments that are sums of zeros in the background state (1, default)
   else if (!std::strcmp(key, "ev_general")) c->opt_ev_general = value ? 1 : 0;   // general-parameter PIHNA / TET4: element-visit kernel with 22 moments (1, default) or the pair kernel (0)
-  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value ? 1 : 0;   // whole-mesh launches of the element-visit kernel as three resident, pipelined workgroups per CU (k_tet4_evq; default 1)
+  else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value == 2 ? 2 : (value ? 1 : 0);   // 2 = also for small launches (tests, tools/ev_timeline.py); whole-mesh launches of the element-visit kernel as three resident, pipelined workgroups per CU (k_tet4_evq; default 1)
   else if (!std::strcmp(key, "evc_occupancy")) c->opt_evc_occ = value == 3 ? 3 : 2;   // k_tet4_evc: waves per SIMD its registers are bounded for
   else if (!std::strcmp(key, "ev_occupancy")) c->opt_ev_occ = value;   // element-visit kernel: 3 (default, 168 registers) or 2
   else if (!std::strcmp(key, "ev_lds")) c->opt_ev_lds = value;   // LDS bytes per workgroup the element-visit clusters are sized for (next rdc_mesh_upload)

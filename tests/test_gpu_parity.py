@@ -115,6 +115,33 @@ def test_parity_ghosted_partition(oracle, strategy):
     assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
 
 
+@pytest.mark.parametrize("pvariant", ["shipped", "realexp_shipped"])
+def test_resident_element_visit_kernel_on_a_ghosted_partition(oracle, pvariant):
+    """k_tet4_evq (the default of large whole-mesh launches; "ev_resident" = 2 runs it at any size): rows of owned nodes only, clusters
+    handed out by the counter over several launches in a row (the record pack kernel resets it), shipped pattern with the integer and
+    a real crowding exponent."""
+    conn, xyz = synth.kuhn_tet_mesh(9, order="random")
+    u = synth.pihna_fields(xyz)
+    d = synth.pihna_param_dict("shipped")
+    if pvariant == "realexp_shipped":
+        d["cells_max_capacity/exponent"] = 2.5
+    p = pihna_params_from_dict(d)
+    n_owned = int(0.6 * xyz.shape[0])
+    conn = conn[(conn < n_owned).any(axis=1)]
+    _, _, val0, rhs0 = oracle.assemble(0, 4, conn, xyz, 5, p, u_old=u, n_owned=n_owned)
+    with AssemblyContext(0) as ctx:
+        ctx.set_option("ev_resident", 2)
+        ctx.mesh_upload(4, conn, xyz, 5, n_owned=n_owned)
+        ctx.field_upload(FIELD_OLD_SOLUTION, u)
+        for _ in range(3):
+            ctx.field_upload(FIELD_OLD_SOLUTION, 0.25 * u)
+            ctx.assemble_pihna(p)
+            ctx.field_upload(FIELD_OLD_SOLUTION, u)
+            ctx.assemble_pihna(p)
+            val, rhs = ctx.csr_download()
+            assert rel(rhs, rhs0) < TOL and rel(val, val0) < TOL
+
+
 def test_parity_cfg2_full_size(oracle):
     """BASELINE configs[1]: PIHNA, K(55) = 998,250 TET4 / 175,616 nodes, shipped parameters."""
     conn, xyz, u, aux, p = _inputs(0, 4, 55, order="lex", variant="shipped")
@@ -398,7 +425,7 @@ def test_two_rank_partitioned_assembly():
                                   {"kernel": 1}, {"occupancy": 1}, {"xcd": 1}, {"prefetch": 16}, {"specialise": 0}, {"moments": 0},
                                   {"stagger": 8}, {"kernel": 6, "grid": 5}, {"kernel": 6, "grid": 5, "moments": 0},
                                   {"ev_persistent": 1}, {"ev_persistent": 1, "grid": 5}, {"ev_persistent": 1, "grid": 1},
-                                  {"ev_resident": 0}, {"ev_resident": 0, "kernel": 7}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1}, {"ev_resident": 1, "grid": 100000}])
+                                  {"ev_resident": 0}, {"ev_resident": 0, "kernel": 7}, {"ev_resident": 2}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1}, {"ev_resident": 1, "grid": 100000}])
 def test_pihna_option_sets(oracle, opts):
     """Every non-default kernel selection (rdc_set_option) of the PIHNA/TET4 path stays on the oracle."""
     conn, xyz = synth.kuhn_tet_mesh(9, order="lex")

@@ -22,7 +22,7 @@ for _ in range(3): ctx.assemble_pihna(p)
 ctx.synchronize(); ms, k = ctx.timing_sum_ms(); base_ms = ms / k
 val0, rhs0 = ctx.csr_download()
 ctx.set_option("kernel", 7); ctx.set_option("ablate", 4)
-ctx.set_option("ev_resident", 1 if evq else 0)
+ctx.set_option("ev_resident", 2 if evq else 0)
 if nodrain: ctx.set_option("stagger", -1)
 nw = C.c_int64()
 ctx._ck(ctx._lib.rdc_debug_stamps(ctx._h, None, 0, C.byref(nw)))
