@@ -244,14 +244,15 @@ struct EvqLists {   // landing area of a cluster's lists (bytes): visit position
   static constexpr int bytes(int nls) { return NL + 2 * nls * 4; }
 };
 }
-template <int EXP_MODE, bool TL>
-__global__ void __launch_bounds__(256, 3)
+// GEN: the 22-moment instantiation (any parameter values), at the register budget of two workgroups per CU as in k_tet4_ev
+template <int EXP_MODE, bool TL, bool GEN = false>
+__global__ void __launch_bounds__(256, GEN ? 2 : 3)
 k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
            const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
            const PihnaK k, const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int nls,
            const int wg_begin, const int wg_count, long long* __restrict__ stamps, const int bg_skip, int* __restrict__ ticket) {
   constexpr int BLOCK = 256, NP = 4;
-  constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
+  constexpr int NM = GEN ? ev::NMG : ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP, later the image halves | R: 5 x MAXN | records: NP x nls x 16 B | lists]
   __shared__ HostPrepEv::Node snode[MAXN];
   __shared__ uint8_t smirror[NBP];
@@ -315,15 +316,16 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     const int w = wg_begin + c0;
     RDC_TS(0);
     {   // zero [M | R] (ds_write_addtid_b32: k_tet4_ev); the image of the previous cluster has been read (barrier at its end)
-      const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)wv * 8192u;
+      constexpr int PER_WAVE = NM * NBP * 8 / 4;   // bytes
+      const uint32_t zbase = (uint32_t)(uintptr_t)lds + (uint32_t)wv * (uint32_t)PER_WAVE;
       const uint32_t zero = 0u;
       uint32_t m0_saved;
-#define RDC_Z4(o) "ds_write_addtid_b32 %1 offset:" #o "\n\tds_write_addtid_b32 %1 offset:" #o "+256\n\tds_write_addtid_b32 %1 offset:" #o "+512\n\tds_write_addtid_b32 %1 offset:" #o "+768\n\t"
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   RDC_Z4(0) RDC_Z4(1024) RDC_Z4(2048) RDC_Z4(3072) RDC_Z4(4096) RDC_Z4(5120) RDC_Z4(6144) RDC_Z4(7168)
-                   "s_mov_b32 m0, %0"
-                   : "=&s"(m0_saved) : "v"(zero), "s"(zbase) : "memory");
-#undef RDC_Z4
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0" : "=&s"(m0_saved) : "s"(zbase) : "memory");
+#pragma unroll
+      for (int o = 0; o < PER_WAVE; o += 1024)
+        asm volatile("ds_write_addtid_b32 %0 offset:%1\n\tds_write_addtid_b32 %0 offset:%1+256\n\tds_write_addtid_b32 %0 offset:%1+512\n\tds_write_addtid_b32 %0 offset:%1+768"
+                     :: "v"(zero), "n"(o) : "memory");
+      asm volatile("s_mov_b32 m0, %0" :: "s"(m0_saved) : "memory");
       if (wv * 64 + lane < 5 * MAXN) lds[NM * NBP + wv * 64 + lane] = 0.0;
     }
     // the one wait of the cluster: what was fetched for it while the previous one was expanded -- and that one's stores
@@ -374,7 +376,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
           for (int j = 0; j < 4; j++) sink.p[i][j] = lds + a + MAXN * (int)((sw[i] >> (4 * j)) & 0xF);
         }
         const bool bg = bg_skip && __builtin_amdgcn_ballot_w64(!ev::pihna_background(U)) == 0;   // k_tet4_ev
-        ev::pihna_visit<EXP_MODE, EvSink<0>, true, false>(k, X, U, r, sink, bg);
+        ev::pihna_visit<EXP_MODE, EvSink<0>, true, GEN>(k, X, U, r, sink, bg);
       }
     }
     RDC_TS(3);
@@ -410,7 +412,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
       if (mirror != blk) {
 #pragma unroll
         for (int m = 0; m < NM; m++)
-          if (ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
+          if (GEN ? ev::symmetric_moment_gen(m) : ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
       }
     }
     {
@@ -700,18 +702,19 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   // when a diagnostic knob of k_tet4_ev is set
   // ... and only for launches of at least 32 clusters per resident workgroup: a workgroup's start (ticket -> node ids -> fetch: three
   // round trips) is not hidden, K(55) = 10,700 clusters runs 0.176 vs 0.159 ms, K(28) 0.049 vs 0.032 ("grid" > 0 forces it: tests)
-  const int evq_grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? a.ev_grid / 2 * 3 : 768);   // three per CU
-  if (a.opt_ev_resident && !E.wg_perm && (!a.opt_ablate || a.opt_ablate == 4) && !a.ev_general && a.opt_ev_occ == 3 && !a.opt_xcd && a.opt_stagger == 0 &&
+  const int evq_grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? (a.ev_general ? a.ev_grid : a.ev_grid / 2 * 3) : 768);   // three per CU (22 moments: two)
+  if (a.opt_ev_resident && !E.wg_perm && (!a.opt_ablate || (a.opt_ablate == 4 && !a.ev_general)) && a.opt_ev_occ == 3 && !a.opt_xcd && a.opt_stagger == 0 &&
       (a.opt_grid > 0 || a.opt_ev_resident == 2 || (int64_t)wg_count >= 32 * (int64_t)evq_grid)) {
     int grid = evq_grid;
     if (grid > wg_count) grid = wg_count;
-    const size_t bytes = ((size_t)ev::NM * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2) * sizeof(double) + EvqLists::bytes(E.nls);
+    const size_t bytes = ((size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2) * sizeof(double) + EvqLists::bytes(E.nls);
     if (!a.ev_ticket) return hipErrorInvalidValue;   // the cluster counter: zeroed by the record pack kernel in front of this launch
-#define RDC_EVQ(MODE, TLV)                                                                                                              \
-  hipLaunchKernelGGL((k_tet4_evq<MODE, TLV>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, \
+#define RDC_EVQ(MODE, TLV, GENV)                                                                                                              \
+  hipLaunchKernelGGL((k_tet4_evq<MODE, TLV, GENV>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, \
                      a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, a.stamps, a.opt_ev_bg, a.ev_ticket)
-    if (a.opt_ablate == 4) { if (a.exp_mode == 3) RDC_EVQ(3, true); else RDC_EVQ(0, true); }
-    else { if (a.exp_mode == 3) RDC_EVQ(3, false); else RDC_EVQ(0, false); }
+    if (a.ev_general) { if (a.exp_mode == 3) RDC_EVQ(3, false, true); else RDC_EVQ(0, false, true); }
+    else if (a.opt_ablate == 4) { if (a.exp_mode == 3) RDC_EVQ(3, true, false); else RDC_EVQ(0, true, false); }
+    else { if (a.exp_mode == 3) RDC_EVQ(3, false, false); else RDC_EVQ(0, false, false); }
 #undef RDC_EVQ
     return hipGetLastError();
   }

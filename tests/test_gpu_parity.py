@@ -443,7 +443,7 @@ def test_pihna_option_sets(oracle, opts):
 
 
 @pytest.mark.parametrize("pvariant", ["full", "realexp", "taxis_v_only"])
-@pytest.mark.parametrize("opts", [{}, {"ev_occupancy": 2}, {"ev_general": 0}, {"specialise": 0}, {"part": 1}])
+@pytest.mark.parametrize("opts", [{}, {"ev_occupancy": 2}, {"ev_general": 0}, {"specialise": 0}, {"part": 1}, {"ev_resident": 2}, {"ev_resident": 2, "grid": 3}])
 def test_pihna_general_parameter_kernels(oracle, pvariant, opts):
     """PIHNA / TET4 with any parameter values: the element-visit kernel with all 22 moments (default, at both register budgets),
     the pair kernel it replaced ("ev_general" = 0), and the general kernel on the shipped values ("specialise" = 0)."""
