@@ -8,8 +8,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 # bench.py configs[] workload prefix -> substrings identifying its kernels (a config's launch = the sum over them)
 CONFIGS = [
     # k_tet4_ev<EXP_MODE, MINW, ABL, GEN>: GEN = false is the shipped parameter pattern (16 moments), true = every term (22 moments)
-    ("cfg2: PIHNA TET4 K(55)", [", false>(rdc::HostPrepEv"], 998250),
-    ("PIHNA TET4 K(119), all transport terms", [", true>(rdc::HostPrepEv", "k_tet4_rg5<rdc::Pihna,"], 10110954),
+    # (k_tet4_evq<EXP_MODE, TL, GEN>: the resident form of large launches)
+    ("cfg2: PIHNA TET4 K(55)", ["k_tet4_ev<3, 3, 0, false>(rdc::HostPrepEv", "k_tet4_ev<0, 3, 0, false>(rdc::HostPrepEv"], 998250),
+    ("PIHNA TET4 K(119), all transport terms", ["k_tet4_ev<3, 2, 0, true>(rdc::HostPrepEv", "k_tet4_evq<3, false, true>(rdc::HostPrepEv", "k_tet4_rg5<rdc::Pihna,"], 10110954),
     ("cfg3: RIPF TET4 K(94), params run/RIPF133/input.dat (shipped)", ["k_tet4_rg5<rdc::RipfReduced", "k_tet4_evc<rdc::RipfReduced"], 4983504),
     ("cfg3: RIPF TET4 K(94), params run/RIPF133/input.dat (full)", ["k_tet4_evc<rdc::Ripf,", "k_tet4_rg5<rdc::Ripf,"], 4983504),
     ("cfg5 (RD half): HCC HEX8 H(126)", ["k_hex8_cl<rdc::Hcc,", "k_hex8_clp<rdc::Hcc,"], 2000376),
