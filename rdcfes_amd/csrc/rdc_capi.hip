@@ -477,7 +477,7 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
   a.opt_ev_resident = c->opt_ev_resident;
   a.opt_ev_bg = c->opt_ev_bg;
   if (c->opt_ev_resident) {   // cluster counter of the resident kernel
-    if ((rc = dev_alloc(c, c->ev_ticket, 64))) return rc;
+    if ((rc = dev_alloc(c, c->ev_ticket, 256))) return rc;   // [0]: whole launches and part 1, [16]: part 2
     a.ev_ticket = (int*)c->ev_ticket.p;
   }
   a.ev_grid = c->opt_grid > 0 ? c->opt_grid : 2 * c->n_cu;

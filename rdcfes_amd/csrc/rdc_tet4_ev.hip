@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(256, GEN ? 2 : 3)
 k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
            const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
            const PihnaK k, const double* __restrict__ rec, double* __restrict__ val, double* __restrict__ rhs, const int nls,
-           const int wg_begin, const int wg_count, long long* __restrict__ stamps, const int bg_skip, int* __restrict__ ticket) {
+           const int wg_begin, const int wg_count, long long* __restrict__ stamps, const int bg_skip, int* __restrict__ ticket,
+           const uint32_t* __restrict__ wg_perm) {
   constexpr int BLOCK = 256, NP = 4;
   constexpr int NM = GEN ? ev::NMG : ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [M: NM x NBP, later the image halves | R: 5 x MAXN | records: NP x nls x 16 B | lists]
@@ -279,6 +280,10 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     c1 = __builtin_amdgcn_readfirstlane(s_tk[0]); c2 = __builtin_amdgcn_readfirstlane(s_tk[1]);
     __syncthreads();
   }
+  // position in the launch's range -> cluster (two-part assembly: the range is a piece of a permuted cluster order).  Uniform
+  // addresses: scalar loads, issued where the position becomes known and used a phase later
+  auto cluster_of = [&](const int c) -> int { return c < wg_count ? (wg_perm ? (int)wg_perm[wg_begin + c] : wg_begin + c) : -1; };
+  int w0c = cluster_of(c0), w1c = cluster_of(c1), w2c = cluster_of(c2);
   long long ts[8];
 #define RDC_TS(x) if (TL) ts[x] = __builtin_amdgcn_s_memtime()
   // everything cluster `w` needs (node ids in `nid`), and the node ids of cluster `w2` into id buffer `nb2`, by LDS-DMA
@@ -301,11 +306,10 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     }
   };
   {
-    const int w0 = wg_begin + c0;
     uint32_t nid0 = 0;
-    if (wv < rounds) nid0 = nlist[(size_t)w0 * nls + threadIdx.x];
+    if (wv < rounds) nid0 = nlist[(size_t)w0c * nls + threadIdx.x];
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(nid0)::"memory");
-    fetch(w0, nid0, c1 < wg_count ? wg_begin + c1 : -1, 1, (int)(threadIdx.x & 63));
+    fetch(w0c, nid0, w1c, 1, (int)(threadIdx.x & 63));
   }
   int tk = NONE;          // lane 0 of wave 0: the ticket requested while the previous cluster was expanded
   bool pending = false;
@@ -313,7 +317,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
   for (int it = 0;; it++) {
     int lane;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));   // recomputed every iteration: never hoisted out of the loop and spilled
-    const int w = wg_begin + c0;
+    const int w = w0c;
     RDC_TS(0);
     {   // zero [M | R] (ds_write_addtid_b32: k_tet4_ev); the image of the previous cluster has been read (barrier at its end)
       constexpr int PER_WAVE = NM * NBP * 8 / 4;   // bytes
@@ -334,7 +338,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     RDC_TS(1);
     lds_barrier();
     RDC_TS(2);
-    if (pending) c2 = __builtin_amdgcn_readfirstlane(s_tk[0]);
+    if (pending) { c2 = __builtin_amdgcn_readfirstlane(s_tk[0]); w2c = cluster_of(c2); }
     if (c0 >= wg_count) break;   // uniform
     {
       const int tid = wv * 64 + lane;
@@ -387,7 +391,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     if (c1 < wg_count) {
       uint32_t nid = 0;
       if (wv < rounds) nid = *reinterpret_cast<const uint32_t*>(lists + EvqLists::NL + (((it + 1) & 1) * nls + wv * 64 + lane) * 4);
-      fetch(wg_begin + c1, nid, c2 < wg_count ? wg_begin + c2 : -1, it & 1, lane);
+      fetch(w1c, nid, w2c, it & 1, lane);
     }
     // the cluster after those two: one ticket per workgroup (nothing left once c2 is past the end: the counter only grows)
     tk = NONE;
@@ -458,12 +462,12 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     }
     RDC_TS(5);
     if (TL && lane == 0 && stamps) {
-      long long* op = stamps + ((int64_t)(w - wg_begin) * 4 + wv) * 12;
+      long long* op = stamps + ((int64_t)c0 * 4 + wv) * 12;
 #pragma unroll
       for (int x = 0; x < 6; x++) op[x] = ts[x];
       op[11] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
-    c0 = c1; c1 = c2;   // c2: from the ticket, behind the barrier at the top
+    c0 = c1; c1 = c2; w0c = w1c; w1c = w2c;   // c2, w2c: from the ticket, behind the barrier at the top
   }
 #undef RDC_TS
 }
@@ -697,13 +701,12 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t acc = (size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
   const size_t lds_doubles = acc > E.max_out_doubles ? acc : E.max_out_doubles;
   const size_t lds_bytes = lds_doubles * sizeof(double);
-  // default for the shipped parameter pattern: pipelined resident workgroups, clusters handed out by a counter.  Not for launches
-  // in a permuted cluster order (two-part assembly: the ticket would need a dependent load), the 22-moment instantiation, or
-  // when a diagnostic knob of k_tet4_ev is set
+  // default: pipelined resident workgroups, clusters handed out by a counter (the two parts of a two-part assembly, which may run
+  // concurrently on two streams, have a counter each: ev_ticket[0] and ev_ticket[16]).  Not when a diagnostic knob of k_tet4_ev is set
   // ... and only for launches of at least 32 clusters per resident workgroup: a workgroup's start (ticket -> node ids -> fetch: three
   // round trips) is not hidden, K(55) = 10,700 clusters runs 0.176 vs 0.159 ms, K(28) 0.049 vs 0.032 ("grid" > 0 forces it: tests)
   const int evq_grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? (a.ev_general ? a.ev_grid : a.ev_grid / 2 * 3) : 768);   // three per CU (22 moments: two)
-  if (a.opt_ev_resident && !E.wg_perm && (!a.opt_ablate || (a.opt_ablate == 4 && !a.ev_general)) && a.opt_ev_occ == 3 && !a.opt_xcd && a.opt_stagger == 0 &&
+  if (a.opt_ev_resident && (!a.opt_ablate || (a.opt_ablate == 4 && !a.ev_general)) && a.opt_ev_occ == 3 && !a.opt_xcd && a.opt_stagger == 0 &&
       (a.opt_grid > 0 || a.opt_ev_resident == 2 || (int64_t)wg_count >= 32 * (int64_t)evq_grid)) {
     int grid = evq_grid;
     if (grid > wg_count) grid = wg_count;
@@ -711,7 +714,7 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
     if (!a.ev_ticket) return hipErrorInvalidValue;   // the cluster counter: zeroed by the record pack kernel in front of this launch
 #define RDC_EVQ(MODE, TLV, GENV)                                                                                                              \
   hipLaunchKernelGGL((k_tet4_evq<MODE, TLV, GENV>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, k, \
-                     a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, a.stamps, a.opt_ev_bg, a.ev_ticket)
+                     a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, a.stamps, a.opt_ev_bg, a.ev_ticket + (a.pack_part == 2 ? 16 : 0), E.wg_perm)
     if (a.ev_general) { if (a.exp_mode == 3) RDC_EVQ(3, false, true); else RDC_EVQ(0, false, true); }
     else if (a.opt_ablate == 4) { if (a.exp_mode == 3) RDC_EVQ(3, true, false); else RDC_EVQ(0, true, false); }
     else { if (a.exp_mode == 3) RDC_EVQ(3, false, false); else RDC_EVQ(0, false, false); }

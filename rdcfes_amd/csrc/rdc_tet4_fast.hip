@@ -914,7 +914,9 @@ static hipError_t pack_nodes(const LaunchArgs& a) {
   if (total > 0) {
     int64_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux, a.packed, a.ev_ticket);
+    hipLaunchKernelGGL((k_pack_nodes<M>), dim3((unsigned)grid), dim3(256), 0, a.stream, nb, ne, a.m.xyz, a.u, a.aux, a.packed, a.ev_ticket ? a.ev_ticket + (a.pack_part == 2 ? 16 : 0) : nullptr);
+  } else if (a.ev_ticket) {   // nothing to pack (a part without ghost nodes): the cluster counter of the launch that follows is still reset
+    (void)hipMemsetAsync(a.ev_ticket + (a.pack_part == 2 ? 16 : 0), 0, sizeof(int), a.stream);
   }
   if (a.pack_part == 1 && a.pack_event) (void)hipEventRecord(a.pack_event, a.stream);
   return hipGetLastError();

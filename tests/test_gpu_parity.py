@@ -476,7 +476,7 @@ def test_pihna_general_parameter_kernels(oracle, pvariant, opts):
     assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
 
 
-@pytest.mark.parametrize("persistent", [0, 1])
+@pytest.mark.parametrize("persistent", [0, 1, 2])
 @pytest.mark.parametrize("frac", [0.0, 0.37, 1.0])
 def test_two_part_assembly_equals_whole(frac, persistent):
     """rdc_set_option("part", 1|2): the rows of the leading workgroups inside [0, interior_nodes) and then the rest give
@@ -488,9 +488,11 @@ def test_two_part_assembly_equals_whole(frac, persistent):
     n_int = int(frac * xyz.shape[0])
     with AssemblyContext(0) as ctx:
         ctx.set_option("interior_nodes", n_int)            # known before the upload: the work lists respect the split
-        if persistent:
+        if persistent == 1:
             ctx.set_option("ev_persistent", 1)             # k_tet4_evp walking over each part's clusters
             ctx.set_option("grid", 7)
+        elif persistent == 2:
+            ctx.set_option("ev_resident", 2)               # k_tet4_evq on each part's piece of the permuted cluster order, a counter per part
         ctx.mesh_upload(4, conn, xyz, 5)
         ctx.field_upload(FIELD_OLD_SOLUTION, u)
         ctx.assemble_pihna(p)
@@ -656,7 +658,8 @@ def test_pihna_shipped_pattern_branches(oracle, moments):
     np.testing.assert_allclose(val[ok], val0[ok], rtol=1e-9, atol=1e-12 * np.abs(val0[ok]).max())
 
 
-def test_two_part_assembly_on_two_streams(oracle):
+@pytest.mark.parametrize("resident", [0, 2])
+def test_two_part_assembly_on_two_streams(oracle, resident):
     """The stream contract of rdc_set_option("part") (include/rdc_assembly.h): part 1 on one stream while the ghost rows
     of the bound solution are rewritten on another, part 2 behind that rewrite on the second stream.  Part 1 must not
     read (or publish) a ghost value, part 2 must see the new ones whatever the order in which the GPU runs the two."""
@@ -674,6 +677,7 @@ def test_two_part_assembly_on_two_streams(oracle):
     lu = u[lp.node_global]
     with AssemblyContext(0) as ctx:
         ctx.set_stream(main_s.cuda_stream)
+        ctx.set_option("ev_resident", resident)             # 2: both parts through k_tet4_evq (one cluster counter per part)
         ctx.mesh_upload(4, lp.conn, lp.xyz, 5, n_owned=lp.n_owned)
         u_t = torch.from_numpy(lu.copy()).to(dev)
         ctx.field_bind_device(FIELD_OLD_SOLUTION, u_t.data_ptr(), u_t.numel())
