@@ -195,7 +195,7 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * transport off), 0 in coefficient form -- same sums, other association; "specialise": 0 disables that parameter-
  * pattern variant altogether; "kernel", "staged", "slim", "stagger", "prefetch", "xcd", "schedule", "block", "grid",
  * "ev_occupancy", "ev_lds", "evc_occupancy", "ev_persistent" (1 = the element-visit kernel as two resident workgroups per CU with a
- * loader wave), "ev_resident" (1, default = whole-mesh launches of at least 32 clusters per resident workgroup run as three resident
+ * loader wave), "ev_resident" (1, default = whole-mesh launches of at least 56 clusters per resident workgroup run as three resident
  * workgroups per CU that fetch the whole next cluster by LDS-DMA while the current one is expanded and copied out, clusters handed
  * out by a counter; 2 = launches of any size; 0 = never) -- "ev_persistent" is experimental and
  * slower than the default -- select alternative / diagnostic kernels.  PIHNA / TET4, element-visit kernel:

@@ -265,21 +265,12 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
   const int rounds = nls >> 6;
   auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // Clusters are handed out dynamically: the first one of a workgroup is blockIdx, every later one comes from a global counter
+  // Clusters are handed out dynamically: the first three of a workgroup are blockIdx + {0, 1, 2} gridDim, every later one comes from a global counter
   // (`ticket`, zero at launch), requested THREE clusters ahead -- the node ids of cluster i + 2 are fetched while cluster i is
   // expanded -- by lane 0 of wave 0 and passed on through LDS at the barrier at the top of the next cluster.  c0 = this cluster,
   // c1, c2 = the next two (indices into the launch's range; >= wg_count: none).
   constexpr int NONE = 0x7fffffff;
-  int c0 = (int)blockIdx.x, c1, c2;
-  {
-    if (threadIdx.x == 0) {
-      const int t = atomicAdd(ticket, 2);
-      s_tk[0] = (int)gridDim.x + t; s_tk[1] = (int)gridDim.x + t + 1;
-    }
-    __syncthreads();
-    c1 = __builtin_amdgcn_readfirstlane(s_tk[0]); c2 = __builtin_amdgcn_readfirstlane(s_tk[1]);
-    __syncthreads();
-  }
+  int c0 = (int)blockIdx.x, c1 = c0 + (int)gridDim.x, c2 = c0 + 2 * (int)gridDim.x;   // the first three of a workgroup are static (no ticket round trip at its start)
   // position in the launch's range -> cluster (two-part assembly: the range is a piece of a permuted cluster order).  Uniform
   // addresses: scalar loads, issued where the position becomes known and used a phase later
   auto cluster_of = [&](const int c) -> int { return c < wg_count ? (wg_perm ? (int)wg_perm[wg_begin + c] : wg_begin + c) : -1; };
@@ -334,7 +325,7 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
     }
     // the one wait of the cluster: what was fetched for it while the previous one was expanded -- and that one's stores
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(tk)::"memory");
-    if (pending && wv == 0 && lane == 0) s_tk[0] = tk == NONE ? NONE : (int)gridDim.x + tk;
+    if (pending && wv == 0 && lane == 0) s_tk[0] = tk == NONE ? NONE : 3 * (int)gridDim.x + tk;
     RDC_TS(1);
     lds_barrier();
     RDC_TS(2);
@@ -703,11 +694,13 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const size_t lds_bytes = lds_doubles * sizeof(double);
   // default: pipelined resident workgroups, clusters handed out by a counter (the two parts of a two-part assembly, which may run
   // concurrently on two streams, have a counter each: ev_ticket[0] and ev_ticket[16]).  Not when a diagnostic knob of k_tet4_ev is set
-  // ... and only for launches of at least 32 clusters per resident workgroup: a workgroup's start (ticket -> node ids -> fetch: three
-  // round trips) is not hidden, K(55) = 10,700 clusters runs 0.176 vs 0.159 ms, K(28) 0.049 vs 0.032 ("grid" > 0 forces it: tests)
+  // ... and only for launches of at least 56 clusters per resident workgroup (43,000 on 256 CUs): a workgroup's start (ticket -> node
+  // ids -> fetch: three round trips) and the tail of the launch are not hidden and cost ~20 us whatever the size -- K(55) = 10,700
+  // clusters runs 0.184 vs 0.167 ms, K(75) 0.388 vs 0.370, K(85) = 40,000 clusters 0.577 vs 0.575, K(94) 0.713 vs 0.737, K(119)
+  // 1.38 vs 1.50 ("grid" > 0 or "ev_resident" = 2 force it: tests)
   const int evq_grid = a.opt_grid > 0 ? a.opt_grid : (a.ev_grid > 0 ? (a.ev_general ? a.ev_grid : a.ev_grid / 2 * 3) : 768);   // three per CU (22 moments: two)
   if (a.opt_ev_resident && (!a.opt_ablate || (a.opt_ablate == 4 && !a.ev_general)) && a.opt_ev_occ == 3 && !a.opt_xcd && a.opt_stagger == 0 &&
-      (a.opt_grid > 0 || a.opt_ev_resident == 2 || (int64_t)wg_count >= 32 * (int64_t)evq_grid)) {
+      (a.opt_grid > 0 || a.opt_ev_resident == 2 || (int64_t)wg_count >= 56 * (int64_t)evq_grid)) {
     int grid = evq_grid;
     if (grid > wg_count) grid = wg_count;
     const size_t bytes = ((size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2) * sizeof(double) + EvqLists::bytes(E.nls);
