@@ -194,10 +194,9 @@ int rdc_set_kernel_variant(rdc_ctx* ctx, int variant);
  * "moments": 1 (default) evaluates PIHNA/TET4 rows in moment form when the parameters have the shipped pattern (cell
  * transport off), 0 in coefficient form -- same sums, other association; "specialise": 0 disables that parameter-
  * pattern variant altogether; "kernel", "staged", "slim", "stagger", "prefetch", "xcd", "schedule", "block", "grid",
- * "ev_occupancy", "ev_lds", "evc_occupancy", "ev_persistent" (1 = the element-visit kernel as two resident workgroups per CU with a
- * loader wave), "ev_resident" (1, default = whole-mesh launches of at least 56 clusters per resident workgroup run as three resident
+ * "ev_occupancy", "ev_lds", "evc_occupancy", "ev_resident" (1, default = whole-mesh launches of at least 56 clusters per resident workgroup run as three resident
  * workgroups per CU that fetch the whole next cluster by LDS-DMA while the current one is expanded and copied out, clusters handed
- * out by a counter; 2 = launches of any size; 0 = never) -- "ev_persistent" is experimental and
+ * out by a counter; 2 = launches of any size; 0 = never) -- the others are experimental and
  * slower than the default -- select alternative / diagnostic kernels.  PIHNA / TET4, element-visit kernel:
  * "ev_general" 1 (default) = any parameter values through the kernel with all 22 moments, 0 = through the (node, element) pair
  * kernel as before round 3; "ev_background" 1 (default) = waves all of whose elements are in the background state of the shipped

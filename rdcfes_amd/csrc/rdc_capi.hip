@@ -69,7 +69,6 @@ struct rdc_ctx {
   int opt_ev_bg = 1;               // 1 = the element-visit kernel skips the zero moments of waves in the background state (n = c = h = a = 0), 0 = evaluates everything
   int opt_ev_general = 1;          // 1 = PIHNA / TET4 with any parameter values through the element-visit kernel with 22 moments; 0 = pair kernel (k_tet4_rg5<Pihna>)
   int opt_ev_resident = 1;         // 1 (default) = whole-mesh launches of the shipped-pattern element-visit kernel run as k_tet4_evq (resident workgroups that fetch the next cluster while this one is expanded); 0 = k_tet4_ev
-  int opt_ev_persist = 0;          // 1 = persistent element-visit kernel with a loader wave (k_tet4_evp)
   int opt_ev_occ = 3;              // launch-bound waves per SIMD of the element-visit kernel (2 or 3)
   int opt_evc_occ = 2;             // ... of the coefficient-form element-visit kernel (k_tet4_evc): 2 (default) or 3 (spills: measured 2.24 vs 1.42 ms)
   int opt_ev_lds = 54000;          // LDS bytes per workgroup the clusters are sized for (3 workgroups per CU)
@@ -473,7 +472,6 @@ int assemble_rd(rdc_ctx* c, const P* p, int nvar_expected, bool need_aux) {
              (!c->stamps.p || (c->opt_kernel == 7 && c->opt_ablate == 4)) && c->opt_occ != 1 && c->opt_ldspad == 0;
   a.opt_ev_occ = c->opt_ev_occ;
   a.opt_evc_occ = c->opt_evc_occ;
-  a.opt_ev_persist = c->opt_ev_persist;
   a.opt_ev_resident = c->opt_ev_resident;
   a.opt_ev_bg = c->opt_ev_bg;
   if (c->opt_ev_resident) {   // cluster counter of the resident kernel
@@ -733,7 +731,6 @@ int rdc_set_option(rdc_ctx* c, const char* key, int value) {
     if (value != 31 && value != 62) return fail(c, RDC_ERR_INVALID, "solid_cl_waves must be 31 (3 consumer + 1 producer waves) or 62");
     c->opt_solid_cl_waves = value;
   }
-  else if (!std::strcmp(key, "ev_persistent")) c->opt_ev_persist = value ? 1 : 0;   // element-visit kernel walking over the clusters (loader wave + compute waves)
   else if (!std::strcmp(key, "ev_background")) c->opt_ev_bg = value ? 1 : 0;   // element-visit kernel: skip the moments that are sums of zeros in the background state (1, default)
   else if (!std::strcmp(key, "ev_general")) c->opt_ev_general = value ? 1 : 0;   // general-parameter PIHNA / TET4: element-visit kernel with 22 moments (1, default) or the pair kernel (0)
   else if (!std::strcmp(key, "ev_resident")) c->opt_ev_resident = value == 2 ? 2 : (value ? 1 : 0);   // 2 = also for small launches (tests, tools/ev_timeline.py); whole-mesh launches of the element-visit kernel as three resident, pipelined workgroups per CU (k_tet4_evq; default 1)

@@ -97,7 +97,7 @@ struct LaunchArgs {
   bool use_ev = false;   // element-visit kernel allowed for this call
   int opt_ev_occ = 3;
   int opt_evc_occ = 2;
-  int opt_ev_persist = 0, ev_grid = 0;   // persistent form of the element-visit kernel (k_tet4_evp) and its grid (workgroups resident at once)
+  int ev_grid = 0;           // 2 x CUs: the resident element-visit kernel launches 3/2 of it (22 moments: all of it)
   int opt_ev_bg = 1;         // k_tet4_ev: waves all of whose visits are in the background state skip the moments that are sums of zeros (rdc_tet4_ev.h, bg)
   int* ev_ticket = nullptr;  // k_tet4_evq: cluster counter (one int, zeroed by the launch)
   bool ev_general = false;   // k_tet4_ev with every PIHNA term on (22 moments) instead of the shipped parameter pattern (16)

@@ -233,7 +233,9 @@ k_tet4_ev(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict_
 // LDS: the record and list landing areas may not be covered by the CSR image, so the image is built and sent in two halves
 // (nodes 0-7 by waves 0-1, nodes 8-15 by waves 2-3: at most 8 x 16 x 25 doubles, inside the 32 KB moment slice); 46 KB per workgroup.
 namespace {
-__device__ __forceinline__ void evl_dma16(const void* g, const void* lds_base) {   // LDS-DMA the compiler does not see (see evp_dma16)
+// LDS-DMA of 16 bytes per lane (lane l lands at lds_base + 16 l), issued where the compiler cannot see it: it guards the next LDS
+// write after a VISIBLE LDS-DMA with s_waitcnt vmcnt(0) (possible alias), which would stall the wave behind every fetch
+__device__ __forceinline__ void evl_dma16(const void* g, const void* lds_base) {
   const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_base);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory", "m0");
 }
@@ -463,206 +465,8 @@ k_tet4_evq(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict
 #undef RDC_TS
 }
 
-// ---- persistent form ("ev_persistent" = 1) ----------------------------------------------------------------------------------
-// k_tet4_ev is bound by what a workgroup WAITS for, not by a pipe: the list loads and the record DMA at its start, and the
-// drain of its stores at its end (s_endpgm waits for them), during which its registers and LDS do nothing.  Here a workgroup
-// stays resident and walks over clusters blockIdx + i * gridDim:
-//   * wave 3 (the wave with the fewest visits) is also the LOADER: at the top of cluster i it issues the record DMA of
-//     cluster i + 1 (node ids already in its registers), the list DMA of cluster i + 1 into the other LDS buffer and the
-//     node-id loads of cluster i + 2, and waits for them at the end of cluster i.  It takes no part in the copy-out: it is
-//     the only wave that waits for vmcnt, and it never has a store in flight;
-//   * waves 0-2 read everything from LDS and never load from memory, so nothing makes them wait for their own stores: the
-//     copy-out of cluster i drains while cluster i + 1 is computed (on gfx9 one counter covers loads and stores, which
-//     return out of order with respect to each other -- a wave that loads cannot let its stores fly).  No scratch for the
-//     same reason: 256-register budget, two workgroups per CU.
-// Barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier); every wave executes the same sequence.
-namespace {
-// LDS-DMA of 16 bytes per lane (lane l lands at lds_base + 16 l), issued where the compiler cannot see it: it guards the
-// next LDS write after a visible LDS-DMA with s_waitcnt vmcnt(0) (possible alias), which would stall the loader wave at
-// the top of every cluster.  The buffers the loader fills are not touched by anyone until the barrier that follows its own wait.
-__device__ __forceinline__ void evp_dma16(const void* g, const void* lds_base) {
-  const uint32_t b = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory", "m0");
-}
-struct EvpLists {   // per-cluster lists in LDS, filled by the loader
-  static constexpr int PL = 0, SL = 1024, MIRROR = SL + 2048, SNODE = MIRROR + 256, DESC = SNODE + 256, BYTES = DESC + 32;
-};
-}
-
-template <int EXP_MODE>
-__global__ void __launch_bounds__(256, 2)
-k_tet4_evp(const HostPrepEv::Desc* __restrict__ desc, const uint32_t* __restrict__ nlist, const uint32_t* __restrict__ vloc,
-           const uint32_t* __restrict__ vslot, const HostPrepEv::Node* __restrict__ ntab, const uint8_t* __restrict__ bpart,
-           const uint32_t* __restrict__ wg_perm, const PihnaK k, const double* __restrict__ rec, double* __restrict__ val,
-           double* __restrict__ rhs, const int nls, const int wg_begin, const int wg_count, const int main_doubles,
-           const int diag /* timing diagnostics (results WRONG), bit mask: 1 = no visits, 2 = no moments -> image, 4 = no copy-out */) {
-  constexpr int BLOCK = 256, NP = 4;
-  constexpr int NM = ev::NM, NBP = ev::NBP, MAXN = ev::MAXN;
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [main: M | R, later the CSR image][records x 2][lists x 2]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wv == 3;
-  const int rec_doubles = NP * nls * 2;
-  const int rounds = nls >> 6;
-  double* const R = lds + NM * NBP;
-  double* const recs0 = lds + main_doubles;
-  char* const lists0 = reinterpret_cast<char*>(recs0 + 2 * rec_doubles);
-  const int n_it = (wg_count - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1: the grid is <= wg_count
-  auto cluster = [&](int i) {
-    int w = wg_begin + (int)blockIdx.x + i * (int)gridDim.x;
-    if (wg_perm) w = (int)wg_perm[w];
-    return w;
-  };
-  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  // ---- loader pieces (wave 3 only) -----------------------------------------------------------------------------------------
-  uint32_t nid[4] = {0u, 0u, 0u, 0u};      // node ids of the NEXT cluster whose records are still to be fetched
-  uint32_t nidn[4] = {0u, 0u, 0u, 0u};     // ... of the one after, in flight
-  auto issue_lists = [&](int w, int b) {
-    char* L = lists0 + b * EvpLists::BYTES;
-    evp_dma16(reinterpret_cast<const char*>(vloc) + ((size_t)w * BLOCK + lane * 4) * 4, L + EvpLists::PL);
-#pragma unroll
-    for (int q = 0; q < 2; q++)   // 8 bytes of column slots per lane: two lanes per 16-byte piece
-      evp_dma16(reinterpret_cast<const char*>(vslot) + (size_t)w * BLOCK * 8 + (size_t)(q * 64 + lane) * 16, L + EvpLists::SL + q * 64 * 16);
-    if (lane < 16) {
-      evp_dma16(reinterpret_cast<const char*>(bpart) + (size_t)w * NBP + lane * 16, L + EvpLists::MIRROR);
-      evp_dma16(reinterpret_cast<const char*>(ntab) + ((size_t)w * MAXN + lane) * 16, L + EvpLists::SNODE);
-    }
-    if (lane < 2) evp_dma16(reinterpret_cast<const char*>(desc) + (size_t)w * 32 + lane * 16, L + EvpLists::DESC);
-  };
-  auto issue_nid = [&](int w, uint32_t (&dst)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (r < rounds) dst[r] = nlist[(size_t)w * nls + r * 64 + lane];
-  };
-  auto issue_records = [&](int b) {
-    double* recs = recs0 + b * rec_doubles;
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (r < rounds) {
-        const char* src = reinterpret_cast<const char*>(rec) + (size_t)nid[r] * (NP * 16);
-#pragma unroll
-        for (int p = 0; p < NP; p++) evp_dma16(src + p * 16, recs + (p * nls + r * 64) * 2);
-      }
-  };
-  // The two roles are separate instantiations of the same loop (the branch is uniform per wave): with the LDS-DMA in its
-  // program order the compiler guards the next LDS write with s_waitcnt vmcnt(0), which in waves 0-2 would wait for their stores.
-  auto run = [&](auto role) {
-  constexpr bool LOADER = decltype(role)::value;
-  // (the loaded node ids pass through the wait statements: the compiler does not look inside them, and a load it still
-  // believes to be in flight costs a vmcnt(0) of its own wherever the register is next touched -- in the middle of the DMA issue)
-  if (LOADER) {
-    issue_lists(cluster(0), 0);
-    issue_nid(cluster(0), nid);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nid[0]), "+v"(nid[1]), "+v"(nid[2]), "+v"(nid[3])::"memory");
-    issue_records(0);
-    if (n_it > 1) issue_nid(cluster(1), nid);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nid[0]), "+v"(nid[1]), "+v"(nid[2]), "+v"(nid[3])::"memory");
-  }
-  lds_barrier();                                     // prologue: cluster 0 is in buffer 0
-  for (int i = 0; i < n_it; i++) {
-    const char* L = lists0 + (i & 1) * EvpLists::BYTES;
-    const double* recs = recs0 + (i & 1) * rec_doubles;
-    const HostPrepEv::Node* snode = reinterpret_cast<const HostPrepEv::Node*>(L + EvpLists::SNODE);
-    const int nown = (int)reinterpret_cast<const HostPrepEv::Desc*>(L + EvpLists::DESC)->nown;
-    if (LOADER && i + 1 < n_it) {
-      issue_records((i + 1) & 1);                    // both buffers of cluster i - 1 are free since barrier (e)
-      issue_lists(cluster(i + 1), (i + 1) & 1);
-    }
-    {
-      double2* z = reinterpret_cast<double2*>(lds);
-      for (int x = tid; x < (NM * NBP + 5 * MAXN) / 2; x += BLOCK) z[x] = make_double2(0.0, 0.0);
-    }
-    if (LOADER && i + 2 < n_it) issue_nid(cluster(i + 2), nidn);   // behind the loop: loads in flight are waited for in front of a loop
-    lds_barrier();                                   // (a)
-    // ---- element visits (phase 1 of k_tet4_ev)
-    const uint32_t pl = reinterpret_cast<const uint32_t*>(L + EvpLists::PL)[tid];
-    if (pl != 0xFFFFFFFFu && !(diag & 1)) {
-      const uint2 sl = reinterpret_cast<const uint2*>(L + EvpLists::SL)[tid];
-      double X[4][3], U[4][5];
-      int li[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        li[j] = (pl >> (8 * j)) & 0xFF;
-        double rr[2 * NP];
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-          const double2 v2 = reinterpret_cast<const double2*>(recs)[p * nls + li[j]];
-          rr[2 * p] = v2.x; rr[2 * p + 1] = v2.y;
-        }
-        X[j][0] = rr[0]; X[j][1] = rr[1]; X[j][2] = rr[2];
-#pragma unroll
-        for (int v = 0; v < 5; v++) U[j][v] = rr[3 + v];
-      }
-      const int r = (li[0] < nown) + (li[1] < nown) + (li[2] < nown) + (li[3] < nown);
-      EvSink<0> sink;
-      const uint32_t sw[4] = {sl.x & 0xFFFFu, sl.x >> 16, sl.y & 0xFFFFu, sl.y >> 16};   // four 4-bit column slots per row
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        const int n = (a < r) ? li[a] : 0;
-        sink.pr[a] = R + n;
-#pragma unroll
-        for (int j = 0; j < 4; j++) sink.p[a][j] = lds + n + MAXN * (int)((sw[a] >> (4 * j)) & 0xF);
-      }
-      ev::pihna_visit<EXP_MODE>(k, X, U, r, sink);
-    }
-    lds_barrier();                                   // (b)
-    // ---- node block tid: moments (+ mirror) -> registers; rhs out (tid < 80: waves 0 and 1)
-    double e[NM];
-    const int bn = tid & (MAXN - 1), bs = tid >> 4;
-    const bool has = bn < nown && bs < (int)snode[bn < nown ? bn : 0].len && !(diag & 2);
-    if (has) {
-      const int mirror = (int)reinterpret_cast<const uint8_t*>(L + EvpLists::MIRROR)[tid];
-#pragma unroll
-      for (int m = 0; m < NM; m++) e[m] = lds[m * NBP + tid];
-      if (mirror != tid) {
-#pragma unroll
-        for (int m = 0; m < NM; m++)
-          if (ev::symmetric_moment(m)) e[m] += lds[m * NBP + mirror];
-      }
-    }
-    if (tid < nown * 5) {
-      const int n = tid / 5, a = tid - n * 5;
-      rhs[(size_t)snode[n].node * 5 + a] = R[a * MAXN + n];
-    }
-    lds_barrier();                                   // (c): every moment has been read, the image may overwrite the slice
-    if (has) {
-      double o[25];
-      ev::pihna_expand(k, e, o);
-      const int len5 = 5 * (int)snode[bn].len;
-      double* dst = lds + snode[bn].obase + 5 * bs;
-#pragma unroll
-      for (int a = 0; a < 5; a++)
-#pragma unroll
-        for (int b = 0; b < 5; b++) dst[a * len5 + b] = o[a * 5 + b];
-    }
-    lds_barrier();                                   // (d)
-    if (!LOADER) {
-      for (int n = wv; n < ((diag & 4) ? 0 : nown); n += 3) {
-        const HostPrepEv::Node nd = snode[n];
-        const int cnt = 25 * (int)nd.len;
-        double* out = val + (size_t)25 * nd.bptr;
-        const double* img = lds + nd.obase;
-        const int sh = (int)(nd.obase & 1);
-        typedef double v2d_t __attribute__((ext_vector_type(2)));
-        const int npair = (cnt - sh) >> 1;
-        const v2d_t* src = reinterpret_cast<const v2d_t*>(img + sh);
-        v2d_t* dstg = reinterpret_cast<v2d_t*>(out + sh);
-        for (int x = lane; x < npair; x += 64) __builtin_nontemporal_store(src[x], dstg + x);
-        if (sh && lane == 0) __builtin_nontemporal_store(img[0], out);
-        if (((cnt - sh) & 1) && lane == 1) __builtin_nontemporal_store(img[cnt - 1], out + cnt - 1);
-      }
-    } else {
-      // cluster i + 1 has arrived (the node ids pass through the statement so that their copy cannot be scheduled, with a
-      // wait of its own, right behind the loads at the top of the cluster)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(nidn[0]), "+v"(nidn[1]), "+v"(nidn[2]), "+v"(nidn[3])::"memory");
-#pragma unroll
-      for (int r = 0; r < 4; r++) nid[r] = nidn[r];
-    }
-    lds_barrier();                                   // (e): the image has been read (into the stores' registers)
-  }
-  };
-  if (loader) run(std::true_type{}); else run(std::false_type{});
-}
+// (A first resident form, k_tet4_evp -- two workgroups per CU, a loader wave, two LDS buffers: 2.45 vs 2.11 ms in round 2 -- was removed at the end of
+// round 3: profiles/r02i_ab_evp.txt)
 
 hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   const EvDev& E = a.ev;
@@ -672,23 +476,6 @@ hipError_t launch_tet4_ev(const LaunchArgs& a, const PihnaK& k) {
   if (a.ev_start) (void)hipEventRecord(a.ev_start, a.stream);
   const int wg_count = E.wg_count < 0 ? E.n_wg - E.wg_begin : E.wg_count;
   if (wg_count <= 0) return hipSuccess;
-  if (a.opt_ev_persist && E.nls <= 256 && !a.ev_general) {   // "ablate" = timing diagnostics of this kernel (bit mask, see its last argument)
-    int grid = a.ev_grid > 0 ? a.ev_grid : 512;
-    if (grid > wg_count) grid = wg_count;
-    const size_t accd = (size_t)ev::NM * ev::NBP + 5 * ev::MAXN;
-    const size_t main_doubles = ((accd > E.max_out_doubles ? accd : E.max_out_doubles) + 1) & ~(size_t)1;
-    const size_t bytes = (main_doubles + (size_t)2 * 4 * E.nls * 2) * sizeof(double) + 2 * EvpLists::BYTES;
-    static std::atomic<uint64_t> attr[2];  /* per instantiation and device */
-    dyn_lds_once(attr[0], (const void*)k_tet4_evp<3>, 160 * 1024);
-    dyn_lds_once(attr[1], (const void*)k_tet4_evp<0>, 160 * 1024);
-    if (a.exp_mode == 3)
-      hipLaunchKernelGGL((k_tet4_evp<3>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, E.wg_perm, k,
-                         a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, (int)main_doubles, a.opt_ablate);
-    else
-      hipLaunchKernelGGL((k_tet4_evp<0>), dim3(grid), dim3(256), bytes, a.stream, E.desc, E.nlist, E.vloc, E.vslot, E.ntab, E.bpart, E.wg_perm, k,
-                         a.packed, a.val, a.rhs, E.nls, E.wg_begin, wg_count, (int)main_doubles, a.opt_ablate);
-    return hipGetLastError();
-  }
   const size_t acc = (size_t)(a.ev_general ? ev::NMG : ev::NM) * ev::NBP + 5 * ev::MAXN + (size_t)4 * E.nls * 2;
   const size_t lds_doubles = acc > E.max_out_doubles ? acc : E.max_out_doubles;
   const size_t lds_bytes = lds_doubles * sizeof(double);

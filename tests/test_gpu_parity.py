@@ -424,7 +424,6 @@ def test_two_rank_partitioned_assembly():
 @pytest.mark.parametrize("opts", [{"kernel": 7}, {"kernel": 7, "ev_occupancy": 2}, {"kernel": 5}, {"slim": 1, "occupancy": 3}, {"slim": 1}, {"kernel": 3}, {"kernel": 4}, {"kernel": 2},
                                   {"kernel": 1}, {"occupancy": 1}, {"xcd": 1}, {"prefetch": 16}, {"specialise": 0}, {"moments": 0},
                                   {"stagger": 8}, {"kernel": 6, "grid": 5}, {"kernel": 6, "grid": 5, "moments": 0},
-                                  {"ev_persistent": 1}, {"ev_persistent": 1, "grid": 5}, {"ev_persistent": 1, "grid": 1},
                                   {"ev_resident": 0}, {"ev_resident": 0, "kernel": 7}, {"ev_resident": 2}, {"ev_resident": 1, "grid": 7}, {"ev_resident": 1, "grid": 1}, {"ev_resident": 1, "grid": 100000}])
 def test_pihna_option_sets(oracle, opts):
     """Every non-default kernel selection (rdc_set_option) of the PIHNA/TET4 path stays on the oracle."""
@@ -476,7 +475,7 @@ def test_pihna_general_parameter_kernels(oracle, pvariant, opts):
     assert rel(val, val0) < TOL and rel(rhs, rhs0) < TOL
 
 
-@pytest.mark.parametrize("persistent", [0, 1, 2])
+@pytest.mark.parametrize("persistent", [0, 2])
 @pytest.mark.parametrize("frac", [0.0, 0.37, 1.0])
 def test_two_part_assembly_equals_whole(frac, persistent):
     """rdc_set_option("part", 1|2): the rows of the leading workgroups inside [0, interior_nodes) and then the rest give
@@ -488,10 +487,7 @@ def test_two_part_assembly_equals_whole(frac, persistent):
     n_int = int(frac * xyz.shape[0])
     with AssemblyContext(0) as ctx:
         ctx.set_option("interior_nodes", n_int)            # known before the upload: the work lists respect the split
-        if persistent == 1:
-            ctx.set_option("ev_persistent", 1)             # k_tet4_evp walking over each part's clusters
-            ctx.set_option("grid", 7)
-        elif persistent == 2:
+        if persistent == 2:
             ctx.set_option("ev_resident", 2)               # k_tet4_evq on each part's piece of the permuted cluster order, a counter per part
         ctx.mesh_upload(4, conn, xyz, 5)
         ctx.field_upload(FIELD_OLD_SOLUTION, u)

@@ -55,7 +55,7 @@ res = {s: [] for s in a.sets}
 cur_block = 2561
 for r in range(a.rounds):
     for s in a.sets:
-        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0); ctx.set_option("specialise", 1); ctx.set_option("slim", 0); ctx.set_option("moments", 1); ctx.set_option("prefetch", 0); ctx.set_option("stagger", 0); ctx.set_option("lds_pad", 0); ctx.set_option("grid", 0); ctx.set_option("ev_occupancy", 3); ctx.set_option("ev_persistent", 0); ctx.set_option("evc_occupancy", 2); ctx.set_option("ev_resident", 1); ctx.set_option("xcd", 0); ctx.set_option("ev_general", 1); ctx.set_option("ev_background", 1)
+        ctx.set_option("occupancy", 2); ctx.set_option("ablate", 0); ctx.set_option("kernel", 0); ctx.set_option("specialise", 1); ctx.set_option("slim", 0); ctx.set_option("moments", 1); ctx.set_option("prefetch", 0); ctx.set_option("stagger", 0); ctx.set_option("lds_pad", 0); ctx.set_option("grid", 0); ctx.set_option("ev_occupancy", 3); ctx.set_option("evc_occupancy", 2); ctx.set_option("ev_resident", 1); ctx.set_option("xcd", 0); ctx.set_option("ev_general", 1); ctx.set_option("ev_background", 1)
         opts = dict(kv.split("=") for kv in s.split(",") if "=" in kv)
         blk = int(opts.pop("block", 256)) * 10 + int(opts.pop("schedule", 1))
         if blk != cur_block:  # work lists depend on the workgroup size / schedule: rebuild
